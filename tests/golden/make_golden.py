@@ -1,0 +1,205 @@
+"""tests/golden/make_golden.py -- generates the committed golden fixtures (build container only).
+
+Imports the REFERENCE's own Python from /root/reference under the stand-in modules of ref_shims.py,
+instantiates its classes (`lvae.get_model('qarv_base')`, `ConvNeXtBlockAdaLN`, `imcoding_evaluate`,
+`pack_byte_strings` ...), loads seeded synthetic weights (lossy-vae_amd/seeded_init.py) and records
+inputs/outputs as small .npz files next to this script.  The fixtures are DATA; no reference source
+text is stored.  Run:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import io
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+spec = importlib.util.spec_from_file_location('seeded_init', os.path.join(REPO, 'lossy-vae_amd', 'seeded_init.py'))
+seeded_init = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(seeded_init)
+
+import lvae  # noqa: E402  (the reference package)
+import lvae.models.common as ref_common  # noqa: E402
+import lvae.utils.coding as ref_coding  # noqa: E402
+from lvae.evaluation import imcoding_evaluate  # noqa: E402
+
+assert lvae.__file__.startswith('/root/reference'), lvae.__file__
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def load_seeded(model, seed=0):
+    sd = model.state_dict()
+    new = {}
+    for k, v in sd.items():
+        a = seeded_init.seeded_tensor(k, tuple(v.shape), seed)
+        new[k] = v if a is None else torch.from_numpy(a)
+    model.load_state_dict(new)
+    return model
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def image_tensor(h, w, seed=0, kind='natural'):
+    u8 = seeded_init.synthetic_image_u8(h, w, seed, kind)
+    return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0), u8
+
+
+@torch.no_grad()
+def golden_cnx_block():
+    """One ConvNeXtBlockAdaLN (common.py:110-161) per (dim, k, mlp_ratio) used on a small map."""
+    out = {}
+    for tag, (dim, k, mlp, h, w) in {'c128k7': (128, 7, 1.5, 9, 11), 'c192k7': (192, 7, 2, 8, 8),
+                                     'c512k3': (512, 3, 3, 4, 6), 'c384k5': (384, 5, 2, 6, 5),
+                                     'c256k7': (256, 7, 1.75, 8, 7), 'c512k1': (512, 1, 4, 2, 3)}.items():
+        blk = ref_common.ConvNeXtBlockAdaLN(dim, 256, kernel_size=k, mlp_ratio=mlp).eval()
+        sd = {kk: torch.from_numpy(seeded_init.seeded_tensor(f'blk.{tag}.{kk}', tuple(v.shape), 0))
+              for kk, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)
+        g = np.random.Generator(np.random.Philox(key=1234 + dim + k))
+        x = torch.from_numpy(g.normal(0, 1, size=(2, dim, h, w)).astype(np.float32))
+        emb = torch.from_numpy(g.normal(0, 1, size=(2, 256)).astype(np.float32))
+        y = blk(x, emb)
+        out[f'{tag}.x'], out[f'{tag}.emb'], out[f'{tag}.y'] = npf(x), npf(emb), npf(y)
+        out[f'{tag}.cfg'] = np.array([dim, k, int(mlp * 1000), h, w])
+    np.savez_compressed(os.path.join(HERE, 'cnx_block.npz'), **out)
+    print('cnx_block.npz', len(out))
+
+
+@torch.no_grad()
+def golden_qarv(model, h, w, lmbs, tag, img_seed=0, full_features=True):
+    im, _ = image_tensor(h, w, img_seed)
+    out = {'hw': np.array([h, w]), 'img_seed': np.array(img_seed), 'lmbs': np.array(lmbs, dtype=np.float64)}
+    for lmb in lmbs:
+        key = f'lmb{int(lmb)}'
+        emb = model._get_lmb_embedding(lmb, n=1)
+        out[f'{key}.emb'] = npf(emb)
+        # encoder features (common.py:89-98)
+        x = model.preprocess_input(im)
+        _, feats = model.encoder(x, emb)
+        for k, v in feats.items():
+            a = npf(v)
+            out[f'{key}.{k}'] = a if (full_features or a.size <= 65536) else a[:, ::4, ::2, ::2]
+        # per-block stats: hook the VRLV blocks while the reference runs compress()
+        recs = []
+        hooks = []
+        for blk in model.dec_blocks:
+            if getattr(blk, 'is_latent_block', False):
+                dg = blk.discrete_gaussian
+                rec = {}
+                recs.append(rec)
+
+                def mk(rec, dg):
+                    orig_bi, orig_c = dg.build_indexes, dg.compress
+
+                    def bi(pv):
+                        idx = orig_bi(pv)
+                        rec['pv'], rec['indexes'] = npf(pv), npf(idx).astype(np.uint8)
+                        return idx
+
+                    def comp(qm, indexes, means=None):
+                        rec['qm'], rec['pm'] = npf(qm), npf(means)
+                        rec['symbols'] = npf(dg.quantize(qm, 'symbols', means)).astype(np.int32)
+                        s = orig_c(qm, indexes, means=means)
+                        rec['string'] = np.frombuffer(s[0], dtype=np.uint8)
+                        return s
+                    dg.build_indexes, dg.compress = bi, comp
+                    return lambda: (setattr(dg, 'build_indexes', orig_bi), setattr(dg, 'compress', orig_c))
+                hooks.append(mk(rec, dg))
+        string = model.compress(im, lmb)
+        for hk in hooks:
+            hk()
+        for bi, rec in enumerate(recs):
+            for k, v in rec.items():
+                out[f'{key}.b{bi}.{k}'] = v
+        out[f'{key}.bitstream'] = np.frombuffer(string, dtype=np.uint8)
+        xhat = model.decompress(string)
+        out[f'{key}.xhat'] = npf(xhat)
+        # coder-independent decoder check (qarv/model.py:365-395): conditional_sample with the true z
+        zs = [torch.from_numpy(r['symbols']).float() + torch.from_numpy(r['pm']) for r in recs]
+        xs = model.conditional_sample(lmb, latents=zs)
+        out[f'{key}.xhat_from_z_maxdiff'] = np.array(float((xs - xhat).abs().max()))
+        # estimated bits from the eval-mode likelihood (qarv/model.py:95-96), for the coder-size check
+        model.eval()
+        _, stats = model.forward_end2end(im, lmb=model.expand_to_tensor(lmb, n=1))
+        bits = [float(st['kl'].sum()) / np.log(2) for st in stats]
+        out[f'{key}.est_bits'] = np.array(bits)
+        print(tag, key, 'bytes', len(string), 'est bits/8', sum(bits) / 8, 'sym range',
+              [(int(r['symbols'].min()), int(r['symbols'].max())) for r in recs],
+              'idx range', [(int(r['indexes'].min()), int(r['indexes'].max())) for r in recs],
+              'dec-vs-sample', float(out[f'{key}.xhat_from_z_maxdiff']))
+    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}.npz'), **out)
+
+
+@torch.no_grad()
+def golden_tables(model):
+    """DiscretizedGaussian.update() tables as produced by the reference subclass (entropy_coding.py:52-82)
+    on top of the CompressAI-semantics stand-in."""
+    dg = model.dec_blocks[0].discrete_gaussian
+    np.savez_compressed(os.path.join(HERE, 'discretized_gaussian_tables.npz'),
+                        scale_table=npf(dg.scale_table), quantized_cdf=npf(dg._quantized_cdf),
+                        cdf_length=npf(dg._cdf_length), offset=npf(dg._offset))
+    print('tables', tuple(dg._quantized_cdf.shape), int(dg._cdf_length.max()))
+
+
+def golden_pack():
+    """pack_byte_strings / unpack_byte_string (lvae/utils/coding.py:26-70) known-answer vectors."""
+    cases = [[b'', b'\x01\x02\x03\x04'], [bytes(range(7)), b'', bytes(range(250, 256))], [b'\xff' * 300]]
+    out = {}
+    for i, c in enumerate(cases):
+        packed = ref_coding.pack_byte_strings(c)
+        assert ref_coding.unpack_byte_string(packed) == c
+        out[f'case{i}.packed'] = np.frombuffer(packed, dtype=np.uint8)
+        out[f'case{i}.lengths'] = np.array([len(s) for s in c])
+        out[f'case{i}.joined'] = np.frombuffer(b''.join(c), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'pack_byte_strings.npz'), **out)
+
+
+@torch.no_grad()
+def golden_imcoding(model):
+    """imcoding_evaluate (lvae/evaluation.py:15-67) on a 3-image synthetic folder of ragged sizes
+    (exercises pad_divisible_by, coding.py:73-91, and the crop in decompress_file, qarv/model.py:581)."""
+    from PIL import Image
+    sizes = [(70, 100), (64, 64), (130, 65)]
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for i, (h, w) in enumerate(sizes):
+            Image.fromarray(seeded_init.synthetic_image_u8(h, w, seed=100 + i)).save(Path(d) / f'im{i}.png')
+        for lmb in (2048.0, 128.0):
+            model.default_lmb = lmb
+            r = imcoding_evaluate(model, d)
+            res[f'lmb{int(lmb)}'] = r
+        model.default_lmb = model.lmb_range[1]
+    with open(os.path.join(HERE, 'imcoding_evaluate.json'), 'w') as f:
+        json.dump({'sizes': sizes, 'seeds': [100, 101, 102], 'results': res}, f, indent=1)
+    print('imcoding', res)
+
+
+def main():
+    golden_pack()
+    golden_cnx_block()
+    model = lvae.get_model('qarv_base')
+    load_seeded(model, 0)
+    model.eval()
+    model.compress_mode()
+    n = sum(p.numel() for p in model.parameters())
+    print('qarv_base params', n / 1e6, 'entries', len(model.state_dict()))
+    golden_tables(model)
+    golden_qarv(model, 64, 64, [2048.0, 16.0, 256.0], '64x64')
+    golden_qarv(model, 128, 192, [2048.0, 64.0], '128x192', img_seed=1, full_features=False)
+    golden_imcoding(model)
+
+
+if __name__ == '__main__':
+    main()

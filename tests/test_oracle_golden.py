@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/qarv_oracle.py) against golden vectors produced by the REFERENCE's own
+classes (tests/golden/make_golden.py, imported from /root/reference in the build container).
+
+Floating-point tolerance: the oracle issues the same PyTorch CPU ops as the reference, so it is
+bit-identical on the generating machine; 2e-5 abs / 1e-5 rel leaves room for a different host CPU
+(other SIMD width => other summation order).  Integer outputs (indexes, symbols, bitstreams) are
+required exact up to a tiny flip budget for the same reason (round() of a value within 1e-6 of .5).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import seeded_init
+from oracle import qarv_oracle
+from oracle import compressai_semantics as cs
+
+FLIP_BUDGET = 2e-3
+
+
+@pytest.fixture(scope='module')
+def oracle_model(qarv_seeded_sd):
+    m = qarv_oracle.QarvOracle(qarv_seeded_sd)
+    m.compress_mode()
+    return m
+
+
+def _img(h, w, seed):
+    u8 = seeded_init.synthetic_image_u8(h, w, seed)
+    return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
+
+
+def test_param_inventory(qarv_seeded_sd):
+    # 93.433 M parameters
+    n = sum(v.size for v in qarv_seeded_sd.values())
+    assert n == 93433400 or abs(n / 1e6 - 93.4334) < 1e-4
+
+
+def test_pack_byte_strings_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pack_byte_strings.npz'))
+    for i in range(3):
+        lengths = g[f'case{i}.lengths'].tolist()
+        joined = g[f'case{i}.joined'].tobytes()
+        parts, o = [], 0
+        for L in lengths:
+            parts.append(joined[o:o + L]); o += L
+        packed = qarv_oracle.pack_byte_strings(parts)
+        assert packed == g[f'case{i}.packed'].tobytes()
+        assert qarv_oracle.unpack_byte_string(packed) == parts
+
+
+def test_tables_match_reference(golden_dir, oracle_model):
+    g = np.load(os.path.join(golden_dir, 'discretized_gaussian_tables.npz'))
+    dg = oracle_model.dg
+    np.testing.assert_array_equal(dg.scale_table.numpy(), g['scale_table'])
+    np.testing.assert_array_equal(dg._quantized_cdf.numpy(), g['quantized_cdf'])
+    np.testing.assert_array_equal(dg._cdf_length.numpy(), g['cdf_length'])
+    np.testing.assert_array_equal(dg._offset.numpy(), g['offset'])
+    # int32[64,249], max length 247 (+2)
+    assert g['quantized_cdf'].shape == (64, 249) and int(g['cdf_length'].max()) == 249
+    # CDF post-conditions
+    for i in range(64):
+        L = int(g['cdf_length'][i])
+        row = g['quantized_cdf'][i, :L]
+        assert row[0] == 0 and row[-1] == 65536 and np.all(np.diff(row) >= 1)
+
+
+def test_cnx_block(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'cnx_block.npz'))
+    for tag in ('c128k7', 'c192k7', 'c512k3', 'c384k5', 'c256k7', 'c512k1'):
+        dim, k, mlp1000, h, w = g[f'{tag}.cfg'].tolist()
+        shapes = qarv_oracle.cnx_shapes('blk', dim, k, mlp1000 / 1000.0)
+        sd = {n: torch.from_numpy(seeded_init.seeded_tensor(f'blk.{tag}.{n[4:]}', s, 0)) for n, s in shapes}
+        y = qarv_oracle.cnx_adaln(sd, 'blk', torch.from_numpy(g[f'{tag}.x']), torch.from_numpy(g[f'{tag}.emb']))
+        np.testing.assert_allclose(y.numpy(), g[f'{tag}.y'], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
+def test_full_model(golden_dir, oracle_model, tag, seed):
+    g = np.load(os.path.join(golden_dir, f'qarv_base_{tag}.npz'))
+    h, w = g['hw'].tolist()
+    im = _img(h, w, seed)
+    for lmb in g['lmbs'].tolist():
+        key = f'lmb{int(lmb)}'
+        tr = oracle_model.encode_trace(im, lmb, code=True)
+        np.testing.assert_allclose(tr['emb'].numpy(), g[f'{key}.emb'], rtol=1e-5, atol=1e-6)
+        for name, v in tr['enc_features'].items():
+            a = v.numpy()
+            ref = g[f'{key}.{name}']
+            if a.shape != ref.shape:
+                a = a[:, ::4, ::2, ::2]
+            np.testing.assert_allclose(a, ref, rtol=1e-4, atol=2e-4)
+        nsym = flips = iflips = 0
+        for bi, blk in enumerate(tr['blocks']):
+            np.testing.assert_allclose(blk['pm'].numpy(), g[f'{key}.b{bi}.pm'], rtol=1e-4, atol=2e-4)
+            np.testing.assert_allclose(blk['pv'].numpy(), g[f'{key}.b{bi}.pv'], rtol=1e-4, atol=2e-4)
+            sym, idx = blk['symbols'].numpy(), blk['indexes'].numpy()
+            nsym += sym.size
+            flips += int((sym != g[f'{key}.b{bi}.symbols']).sum())
+            iflips += int((idx != g[f'{key}.b{bi}.indexes']).sum())
+        assert flips <= FLIP_BUDGET * nsym and iflips <= FLIP_BUDGET * nsym, (flips, iflips, nsym)
+        string = oracle_model.compress(im, lmb)
+        if flips == 0 and iflips == 0:
+            assert string == g[f'{key}.bitstream'].tobytes()
+        xhat = oracle_model.decompress(string)
+        np.testing.assert_allclose(xhat.numpy(), g[f'{key}.xhat'], rtol=0, atol=1e-4 if flips == 0 else 5e-2)
+        assert float(g[f'{key}.xhat_from_z_maxdiff']) == 0.0
+        zs = [b['z'] for b in tr['blocks']]
+        x2 = oracle_model.decode_from_latents(lmb, zs)
+        assert float((x2 - xhat).abs().max()) <= 1e-6
+
+
+def test_imcoding_evaluate_contract(golden_dir, oracle_model, tmp_path):
+    """lvae/evaluation.py:15-67 semantics: bpp over ORIGINAL pixels incl. 4-byte (h,w) header; PSNR on the
+    un-rounded float reconstruction; mean of per-image values; ragged sizes padded (coding.py:73-91)."""
+    import math, struct
+    with open(os.path.join(golden_dir, 'imcoding_evaluate.json')) as f:
+        G = json.load(f)
+    for key, ref in G['results'].items():
+        lmb = float(key[3:])
+        acc = {'bpp': [], 'mse': [], 'psnr': []}
+        for (h, w), seed in zip(G['sizes'], G['seeds']):
+            u8 = seeded_init.synthetic_image_u8(h, w, seed)
+            pad = qarv_oracle.pad_divisible_by_u8(u8, 64)
+            im = torch.from_numpy(pad).permute(2, 0, 1).float().div(255).unsqueeze(0)
+            body = oracle_model.compress(im, lmb)
+            blob = struct.pack('2H', h, w) + body                      # qarv/model.py:567-570
+            xhat = oracle_model.decompress(blob[4:])[:, :, :h, :w].squeeze(0)
+            real = torch.from_numpy(u8).permute(2, 0, 1).float().div(255)
+            mse = (real - xhat).square().mean().item()
+            acc['bpp'].append(len(blob) * 8 / float(h * w))
+            acc['mse'].append(mse)
+            acc['psnr'].append(-10 * math.log10(mse))
+        for k in acc:
+            assert abs(np.mean(acc[k]) - ref[k]) <= 2e-3 * abs(ref[k]) + 1e-6, (key, k, np.mean(acc[k]), ref[k])
