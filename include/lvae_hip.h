@@ -1,0 +1,158 @@
+/*
+ * include/lvae_hip.h -- C ABI of liblvae_hip.so, the MI355X-native (gfx950) drop-in for the native code the
+ * reference's QARV / QRes-VAE encode+decode hot path reaches.
+ *
+ * The reference (duanzhiihao/lossy-vae) is 100% Python; its hot path crosses into native code only through
+ * third-party packages:
+ *   - CompressAI pybind11 entry points  RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes /
+ *     pmf_to_quantized_cdf, reached at  lvae/models/qarv/model.py:107,113,124  and
+ *     lvae/models/qresvae/model.py:325,339,356  -> replaced by the `lvae_rans_*` / `lvae_pmf_*` host functions;
+ *   - ATen/cuDNN/cuBLAS kernels behind  lvae/models/common.py:142-161 (ConvNeXtBlockAdaLN.forward),
+ *     common.py:29-38 (patch_downsample / patch_upsample), qarv/model.py:36-39,44-75 (prior / posterior /
+ *     z_proj convs, softplus/exp, build_indexes, quantize)  -> replaced by the `lvae_*_f32` device launchers.
+ *
+ * Conventions
+ *   - Plain C: raw pointers + sizes; no torch types.  Device pointers are owned by the caller (in the Python
+ *     host they are torch tensors' data_ptr()); all device launchers are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) and return a hipError_t as int (0 = success),
+ *     or a negative value for argument errors detected on the host.
+ *   - Activations are NHWC fp32 ([B][H][W][C], C contiguous); a "row" m is one pixel (b,h,w).
+ *   - Host coder functions are thread-safe and stateless (no globals); caller owns all buffers.
+ *   - Entropy-coder streams are byte-compatible with the oracle restatement of CompressAI's rANS
+ *     (oracle/rans_oracle.c): 64-bit rANS (ryg rans64), 16-bit precision, 4-bit bypass escapes.
+ */
+#ifndef LVAE_HIP_H
+#define LVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------ meta */
+int lvae_abi_version(void);          /* bumps on any signature change */
+const char* lvae_build_info(void);   /* "gfx950 hipcc <ver> ..." */
+
+/* ------------------------------------------------------------------------------------------------ host coder
+ * Replaces compressai._CXX.pmf_to_quantized_cdf(list[float], int) -> list[int]
+ * (called from GaussianConditional.update(): qarv/model.py:123-124, qresvae/model.py:317-325).
+ * cdf_out has n+1 entries.  Returns 0, or -1 (negative / non-finite pmf), -2 (zero total), -3 (cannot fix up). */
+int lvae_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf_out);
+
+/* Whole-table builder (GaussianConditional.update() semantics): for each of n_scales scales
+ * c=ceil(scale*m), len=2c+1, pmf[k]=Phi((.5-|k-c|)/s)-Phi((-.5-|k-c|)/s) in fp32, tail=2*lower[0],
+ * row=pmf_to_quantized_cdf([pmf, tail]).  cdf_form: 0 = erf form 0.5*(1+erf(x/sqrt2)) (DiscretizedGaussian,
+ * lvae/models/entropy_coding.py:81-82), 1 = erfc form 0.5*erfc(-x/sqrt2) (stock GaussianConditional, qres34m).
+ * `multiplier` = -ppf(tail_mass/2) (6.10941... for 1e-9).  qcdf is [n_scales][row_stride] int32, zero-filled
+ * beyond each row's length; cdf_len[i]=len_i+2; offset[i]=-c_i.  Returns max row length (+2) or <0.
+ * NOTE: uses the C library's erff/erfcf; the Python host's update() uses torch ops exactly like the reference
+ * so that tables are bit-identical to it -- this entry point is for non-Python integrators. */
+int lvae_build_gaussian_tables(const float* scale_table, int n_scales, double multiplier, int cdf_form,
+                               int32_t* qcdf, int row_stride, int32_t* cdf_len, int32_t* offset);
+
+/* Replaces RansEncoder().encode_with_indexes(symbols, indexes, cdfs, cdf_sizes, offsets) -> bytes
+ * (qarv/model.py:107 via GaussianConditional.compress).  One call = one self-contained stream.
+ * Returns bytes written (multiple of 4, >= 8) or <0: -2 = out_cap too small, -4 = bad index. */
+long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t* idx, size_t n,
+                                   const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                   const int32_t* offset, uint8_t* out, size_t out_cap);
+
+/* Replaces RansDecoder().decode_with_indexes(bytes, indexes, cdfs, cdf_sizes, offsets) -> list[int]
+ * (qarv/model.py:113 via GaussianConditional.decompress).  Returns 0 or <0 (-1 malformed, -3 overrun). */
+int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,
+                                  const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                  const int32_t* offset, int32_t* sym_out);
+
+/* Batched variants: n_streams independent streams coded by up to n_threads host threads (0 = hardware
+ * concurrency).  Stream s uses sym[s]/idx[s]/n[s]; outputs land in out[s] (capacity out_cap[s]) and
+ * out_len[s] receives the byte count (or the negative error).  Returns 0 if all streams succeeded. */
+int lvae_rans_encode_batch(int n_streams, const int32_t* const* sym, const uint8_t* const* idx, const size_t* n,
+                           const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                           uint8_t* const* out, const size_t* out_cap, long* out_len, int n_threads);
+int lvae_rans_decode_batch(int n_streams, const uint8_t* const* in, const size_t* in_len,
+                           const uint8_t* const* idx, const size_t* n,
+                           const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                           int32_t* const* sym_out, int* status, int n_threads);
+
+/* ------------------------------------------------------------------------------------------------ device kernels
+ * GEMM family: out[m][n] = epilogue( sum_k A[m][k] * Wt[n][k] + bias[n] ), fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32.  Replaces timm Mlp fc1/fc2 (common.py:131-132,154), conv 1x1 (qarv/model.py:36,38,39;
+ * common.py:33-38), conv k=s patch_downsample (common.py:29-30) and the 3x3 posterior head (qarv/model.py:37). */
+enum {
+    LVAE_A_PLAIN  = 0,  /* A row m = [A0[m*lda0 .. +K0) , A1[m*lda1 .. +K1)]   (A1 optional: fused torch.cat) */
+    LVAE_A_PATCH2 = 1,  /* 2x2/stride-2 patches of an NHWC [B][2H][2W][Cin] map; K = 4*Cin, order (i,j,ci)    */
+    LVAE_A_CONV3  = 2   /* 3x3/pad-1 taps of an NHWC [B][H][W][Cin] map;       K = 9*Cin, order (i,j,ci)      */
+};
+enum {
+    LVAE_EPI_BIAS       = 0,  /* acc + bias                                                                   */
+    LVAE_EPI_BIAS_GELU  = 1,  /* gelu_erf(acc + bias)                 (fc1, common.py:132 nn.GELU exact form) */
+    LVAE_EPI_GAMMA_RES  = 2,  /* res + gamma[n]*(acc + bias)          (fc2 + layer-scale + shortcut, :157-160) */
+    LVAE_EPI_RES        = 3   /* res + acc + bias                     (fuse_feature_and_z, qarv/model.py:72-75) */
+};
+enum {
+    LVAE_ST_ROWMAJOR    = 0,  /* out[m*ldo + n]                                                               */
+    LVAE_ST_SHUFFLE     = 2,  /* PixelShuffle(r) into NHWC [B][H*r][W*r][N/r^2]; columns pre-permuted to
+                                 n' = (i*r+j)*Cout + c  (common.py:33-38)                                     */
+    LVAE_ST_IMAGE       = 3   /* final layer: PixelShuffle(r) + clamp(-1,1)*0.5+0.5 into NCHW [B][N/r^2][H*r][W*r];
+                                 columns in the reference order n = c*r^2 + i*r + j (qarv/model.py:224-232)  */
+};
+typedef struct {
+    const float* A0; const float* A1;     /* A sources (A1 may be NULL) */
+    long lda0, lda1;                      /* row strides in floats (PLAIN) */
+    int  K0, K1;                          /* PLAIN: lengths of the two sources; PATCH2/CONV3: K0 = Cin */
+    int  H, W;                            /* PATCH2/CONV3/SHUFFLE/IMAGE: spatial size of the row grid (rows = B*H*W) */
+    const float* Wt; long ldw;            /* weights [N][K], K contiguous */
+    const float* bias;                    /* [N] */
+    const float* gamma;                   /* [N]  (EPI_GAMMA_RES) */
+    const float* res; long ldres;         /* residual rows (EPI_GAMMA_RES / EPI_RES); may alias out */
+    float* out; long ldo;
+    int  M, N, K;                         /* K = total reduction length */
+    int  a_mode, epi, store, r;           /* r = pixel-shuffle factor */
+} lvae_gemm_desc;
+int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
+
+/* Depthwise kxk conv (+bias) -> LayerNorm over C (eps 1e-6, biased variance, no affine) -> AdaLN
+ * y*(1+scale)+shift, one pass over an NHWC map (common.py:145-152).  wt is [k*k][C] (tap-major), `ln_w`/`ln_b`
+ * (optional, may be NULL) are the LayerNorm affine of qres34m's MyConvNeXtBlock (qresvae/model.py:168-182);
+ * `shift`/`scale1p` (optional) are the per-lambda AdaLN vectors with scale1p = 1+scale.
+ * Supported: k in {1,3,5,7}; C in {128,192,256,384,512}.  Returns -22 for unsupported shapes. */
+int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                       const float* shift, const float* scale1p, float* y,
+                       int B, int H, int W, int C, int k, void* stream);
+
+/* Stem: NCHW image [B][3][H][W] in [0,1] -> (im+shift)*scale (qarv/model.py:221) -> conv 4x4/stride 4
+ * (zoo.py:37) -> NHWC [B][H/4][W/4][Cout].  wt is [48][Cout] with k = (ci*4+i)*4+j. Cout <= 256, multiple of 64. */
+int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out,
+                  int B, int H, int W, int Cout, float im_shift, float im_scale, void* stream);
+
+/* y[n] = (gelu_out? gelu : id)( sum_k Wt[n][k] * (gelu_in? gelu(x[k]) : x[k]) + b[n] ) -- the lambda-embedding
+ * MLP (qarv/model.py:206-210) and all AdaLN `embedding_layer`s (common.py:123-127) as one concatenated GEMV. */
+int lvae_gemv_f32(const float* Wt, const float* b, const float* x, float* y, int N, int K,
+                  int gelu_in, int gelu_out, void* stream);
+
+/* Prior epilogue (qarv/model.py:51-53 + GaussianConditional.build_indexes, :106,112): prm is the `prior` conv
+ * output [M][2z] (NHWC rows; first z = mean, last z = log-scale).  Writes pm [M][z] and, per image b, the scale
+ * index of every latent element in the coder's NCHW raster order idx[b][c][h][w] (uint8 0..n_scales-1):
+ *   pv = exp(softplus(x+2.3)-2.3); s = max(pv, bound); idx = #{i < n_scales-1 : table[i] < s}. */
+int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
+                         float scale_bound, int B, int HW, int z, void* stream);
+
+/* GaussianConditional.quantize (qarv/model.py:107-108): sym = int32(rint_half_even(qm - pm)) in NCHW raster order
+ * per image, zhat = float(sym) + pm in NHWC. */
+int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, void* stream);
+/* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order. */
+int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, void* stream);
+
+/* Broadcast a [C] vector to all M rows (get_bias, qarv/model.py:289-292). */
+int lvae_bias_expand_f32(const float* bias, float* out, long M, int C, void* stream);
+
+/* sum over all elements of (a-b)^2 per image into out[b] (double), for PSNR (lvae/evaluation.py:47-49);
+ * out must be zeroed by the caller. */
+int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, int B, long n_per_image, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVAE_HIP_H */

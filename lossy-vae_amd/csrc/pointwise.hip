@@ -1,0 +1,377 @@
+// pointwise.hip -- the HBM-bound kernels of the QARV / QRes-VAE hot path for gfx950 (MI355X).
+//
+//  * lvae_dwconv_ln_f32 : depthwise kxk conv + bias -> LayerNorm(C) -> (affine) -> AdaLN, one pass over an NHWC map
+//                         (lvae/models/common.py:145-152; qresvae/model.py:168-176).  Replaces cuDNN depthwise conv,
+//                         2 permute().contiguous() copies, ATen layer_norm and ~6 elementwise launches per block.
+//  * lvae_stem_f32      : preprocess_input (qarv/model.py:221) fused into the 4x4/s4 stem conv (zoo.py:37).
+//  * lvae_gemv_f32      : lambda-embedding MLP + all AdaLN embedding layers (common.py:123-127) as one GEMV.
+//  * lvae_prior_index_f32 / lvae_quantize_f32 / lvae_dequantize_f32 : softplus/exp/LowerBound/build_indexes/quantize
+//                         (qarv/model.py:51-53,106-108,112-113): one launch instead of >= 126 compare/sub launches.
+//
+// All are bandwidth-bound integer/float streaming kernels: the design rules are 16-B per-lane coalesced NHWC
+// accesses, wave64 shuffles for the per-pixel reductions, and >> 256 workgroups per launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lvae_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------------ dwconv + LN + AdaLN
+// A wave64 is split into 64/LPP pixel groups; each group of LPP lanes owns TW consecutive output pixels of one image
+// row and all C = 4*VPL*LPP channels (lane cl holds float4 channel chunks cl, cl+LPP, ...).  The kxk window slides
+// along W in registers: (TW+k-1) input float4 per kernel row feed TW outputs, i.e. ~(TW+k-1)/TW loads per output tap
+// row instead of k.  LayerNorm statistics are reduced across the LPP lanes with xor-shuffles (two-pass variance on the
+// register-resident conv outputs).
+template <int KS, int VPL, int LPP>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, const float* __restrict__ shift,
+                                                        const float* __restrict__ scale1p, float* __restrict__ y,
+                                                        int B, int H, int W, int gpr, long total_groups) {
+    constexpr int TW = 4;
+    constexpr int C = 4 * VPL * LPP;
+    constexpr int GPW = 64 / LPP;
+    constexpr int P = (KS - 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long g = wave_g * GPW + lane / LPP;
+    const int cl = lane % LPP;
+    const bool active = g < total_groups;
+    const long gg = active ? g : total_groups - 1;
+    const int w0 = (int)(gg % gpr) * TW;
+    const long bh = gg / gpr;
+    const int h = (int)(bh % H);
+    const long brow = bh - h;      // b*H
+
+    f32x4 acc[VPL][TW];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int c = 4 * (cl + v * LPP);
+        const f32x4 bv = *(const f32x4*)(bias + c);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[v][t] = bv;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int hh = h + i - P;
+            const bool rv = (hh >= 0) && (hh < H);
+            const float* xrow = x + ((brow + hh) * W) * (long)C + c;
+            f32x4 xr[TW + KS - 1];
+#pragma unroll
+            for (int q = 0; q < TW + KS - 1; ++q) {
+                const int ww = w0 + q - P;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                xr[q] = (rv && ww >= 0 && ww < W) ? *(const f32x4*)(xrow + (long)ww * C) : z;
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const f32x4 wv = *(const f32x4*)(wt + (long)(i * KS + j) * C + c);
+#pragma unroll
+                for (int t = 0; t < TW; ++t) {
+                    acc[v][t][0] = fmaf(xr[t + j][0], wv[0], acc[v][t][0]);
+                    acc[v][t][1] = fmaf(xr[t + j][1], wv[1], acc[v][t][1]);
+                    acc[v][t][2] = fmaf(xr[t + j][2], wv[2], acc[v][t][2]);
+                    acc[v][t][3] = fmaf(xr[t + j][3], wv[3], acc[v][t][3]);
+                }
+            }
+        }
+    }
+
+    const float inv_c = 1.0f / (float)C;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) s += (acc[v][t][0] + acc[v][t][1]) + (acc[v][t][2] + acc[v][t][3]);
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = acc[v][t][e] - mean;
+                acc[v][t][e] = dlt;
+                sq = fmaf(dlt, dlt, sq);
+            }
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
+        const int ww = w0 + t;
+        if (active && ww < W) {
+            float* yp = y + ((bh * W) + ww) * (long)C;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int c = 4 * (cl + v * LPP);
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = acc[v][t][e] * rstd;
+                if (ln_w) {
+                    const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
+                }
+                if (shift) {
+                    const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
+                }
+                *(f32x4*)(yp + c) = o4;
+            }
+        }
+    }
+}
+
+template <int KS, int VPL, int LPP>
+int launch_dwln(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+    const int gpr = (W + 3) / 4;
+    const long total = (long)B * H * gpr;
+    const int gpw = 64 / LPP;
+    const long waves = (total + gpw - 1) / gpw;
+    const long blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL((dwconv_ln_kernel<KS, VPL, LPP>), dim3((unsigned)blocks), dim3(256), 0, st, x, wt, bias, ln_w, ln_b,
+                       shift, scale1p, y, B, H, W, gpr, total);
+    return (int)hipGetLastError();
+}
+
+template <int KS>
+int dispatch_dwln_c(int C, const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                    const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+    switch (C) {
+        case 128: return launch_dwln<KS, 2, 16>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 192: return launch_dwln<KS, 3, 16>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 256: return launch_dwln<KS, 2, 32>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 384: return launch_dwln<KS, 3, 32>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 512: return launch_dwln<KS, 4, 32>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    }
+    return -22;
+}
+
+// ------------------------------------------------------------------------------------------------ stem
+// One block = 64 output pixels x Cout channels (thread n = output channel, its 48 weights live in registers; the
+// 64x48 preprocessed patch matrix is staged in LDS and read as wave-uniform broadcasts).
+__global__ void stem_kernel(const float* __restrict__ im, const float* __restrict__ wt, const float* __restrict__ bias,
+                            float* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M) {
+    __shared__ __attribute__((aligned(16))) float patch[64][48];
+    const int n = threadIdx.x;
+    const int Ho = H / 4, Wo = W / 4;
+    const long p0 = (long)blockIdx.x * 64;
+    for (int e = n; e < 64 * 48; e += blockDim.x) {
+        const int j = e & 3, p = (e >> 2) & 63, ci_i = e >> 8;       // ci_i = ci*4 + i
+        const long pg = p0 + p;
+        float v = 0.f;
+        if (pg < M) {
+            const int wo = (int)(pg % Wo);
+            const long bho = pg / Wo;
+            const int ho = (int)(bho % Ho);
+            const long b = bho / Ho;
+            const int ci = ci_i >> 2, i = ci_i & 3;
+            v = im[((b * 3 + ci) * H + (4 * ho + i)) * (long)W + 4 * wo + j];
+            v = (v + im_shift) * im_scale;
+        }
+        patch[p][ci_i * 4 + j] = v;
+    }
+    float wr[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) wr[k] = wt[k * Cout + n];
+    const float bv = bias[n];
+    __syncthreads();
+    for (int p = 0; p < 64; ++p) {
+        const long pg = p0 + p;
+        if (pg >= M) break;
+        float a = bv;
+#pragma unroll
+        for (int k4 = 0; k4 < 12; ++k4) {
+            const f32x4 pv = *(const f32x4*)&patch[p][k4 * 4];
+            a = fmaf(pv[0], wr[k4 * 4 + 0], a);
+            a = fmaf(pv[1], wr[k4 * 4 + 1], a);
+            a = fmaf(pv[2], wr[k4 * 4 + 2], a);
+            a = fmaf(pv[3], wr[k4 * 4 + 3], a);
+        }
+        out[pg * Cout + n] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gemv
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ Wt, const float* __restrict__ b,
+                                                   const float* __restrict__ x, float* __restrict__ y, int N, int K,
+                                                   int gelu_in, int gelu_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 wv = *(const f32x4*)(Wt + (long)n * K + k);
+        f32x4 xv = *(const f32x4*)(x + k);
+        if (gelu_in) { xv[0] = gelu_erf(xv[0]); xv[1] = gelu_erf(xv[1]); xv[2] = gelu_erf(xv[2]); xv[3] = gelu_erf(xv[3]); }
+        s = fmaf(wv[0], xv[0], s); s = fmaf(wv[1], xv[1], s); s = fmaf(wv[2], xv[2], s); s = fmaf(wv[3], xv[3], s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        s += b[n];
+        y[n] = gelu_out ? gelu_erf(s) : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ entropy parameters
+__global__ void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
+                                   const float* __restrict__ table, int n_scales, float bound, long total, int HW, int z) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*z + c
+    if (e >= total) return;
+    const long m = e / z;
+    const int c = (int)(e - m * z);
+    const float mean = prm[m * 2 * z + c];
+    const float lv = prm[m * 2 * z + z + c];
+    // softplus(x + 2.3) - 2.3  (torch: beta=1, threshold=20)
+    const float xs = lv + 2.3f;
+    const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
+    const float pv = expf(sp - 2.3f);
+    const float s = fmaxf(pv, bound);
+    // idx = #{i < n_scales-1 : table[i] < s}   (binary search, table ascending)
+    int lo = 0, hi = n_scales - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (table[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    pm[e] = mean;
+    const long b = m / HW;
+    const int p = (int)(m - b * HW);
+    idx[(b * z + c) * HW + p] = (uint8_t)lo;
+}
+
+__global__ void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
+                                float* __restrict__ zhat, long total, int HW, int z) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long m = e / z;
+    const int c = (int)(e - m * z);
+    const float mu = pm[e];
+    const float r = rintf(qm[e] - mu);          // v_rndne_f32: round-half-to-even == torch.round
+    zhat[e] = r + mu;
+    const long b = m / HW;
+    const int p = (int)(m - b * HW);
+    sym[(b * z + c) * HW + p] = (int32_t)r;
+}
+
+__global__ void dequantize_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ zhat,
+                                  long total, int HW, int z) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long m = e / z;
+    const int c = (int)(e - m * z);
+    const long b = m / HW;
+    const int p = (int)(m - b * HW);
+    zhat[e] = (float)sym[(b * z + c) * HW + p] + pm[e];
+}
+
+__global__ void bias_expand_kernel(const float* __restrict__ bias, float* __restrict__ out, long total4, int C4) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    ((f32x4*)out)[e] = ((const f32x4*)bias)[e % C4];
+}
+
+__global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    double* __restrict__ out, long n) {
+    const int img = blockIdx.y;
+    const float* pa = a + (long)img * n;
+    const float* pb = b + (long)img * n;
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float dlt = pa[i] - pb[i];
+        s += (double)dlt * (double)dlt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + img, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+}  // namespace
+
+extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                                  const float* shift, const float* scale1p, float* y, int B, int H, int W, int C, int k,
+                                  void* stream) {
+    if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
+    if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 3: return dispatch_dwln_c<3>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 5: return dispatch_dwln_c<5>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 7: return dispatch_dwln_c<7>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    }
+    return -22;
+}
+
+extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out, int B, int H, int W,
+                             int Cout, float im_shift, float im_scale, void* stream) {
+    if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256 || (Cout & 63)) return -22;
+    const long M = (long)B * (H / 4) * (W / 4);
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
+                       B, H, W, Cout, im_shift, im_scale, M);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_gemv_f32(const float* Wt, const float* b, const float* x, float* y, int N, int K, int gelu_in,
+                             int gelu_out, void* stream) {
+    if (!Wt || !b || !x || !y || N <= 0 || K <= 0 || (K & 3)) return -22;
+    hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, Wt, b, x, y, N, K, gelu_in,
+                       gelu_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
+                                    float scale_bound, int B, int HW, int z, void* stream) {
+    if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || HW <= 0 || z <= 0) return -22;
+    const long total = (long)B * HW * z;
+    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prm, pm,
+                       idx, scale_table, n_scales, scale_bound, total, HW, z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z,
+                                 void* stream) {
+    if (!qm || !pm || !sym || !zhat || B <= 0 || HW <= 0 || z <= 0) return -22;
+    const long total = (long)B * HW * z;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
+                       zhat, total, HW, z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, void* stream) {
+    if (!sym || !pm || !zhat || B <= 0 || HW <= 0 || z <= 0) return -22;
+    const long total = (long)B * HW * z;
+    hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm,
+                       zhat, total, HW, z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_bias_expand_f32(const float* bias, float* out, long M, int C, void* stream) {
+    if (!bias || !out || M <= 0 || C <= 0 || (C & 3)) return -22;
+    const long total4 = M * (C / 4);
+    hipLaunchKernelGGL(bias_expand_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bias,
+                       out, total4, C / 4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, int B, long n_per_image, void* stream) {
+    if (!a || !b || !out || B <= 0 || n_per_image <= 0) return -22;
+    long bx = (n_per_image + 256 * 8 - 1) / (256 * 8);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(sqerr_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       n_per_image);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_abi_version(void) { return 1; }
+extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

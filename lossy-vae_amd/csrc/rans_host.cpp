@@ -1,0 +1,269 @@
+// rans_host.cpp -- host entropy coder of liblvae_hip.so (C ABI in include/lvae_hip.h).
+//
+// MI355X-native replacement for the CompressAI pybind11 entry points the reference reaches at
+// lvae/models/qarv/model.py:107 (encode_with_indexes), :113 (decode_with_indexes), :124 (pmf_to_quantized_cdf)
+// and lvae/models/qresvae/model.py:325,339,356.  The range coder stays on the host (serial by nature) but is
+// fed directly by GPU-produced uint8 scale indexes / int32 symbols in pinned buffers: no Python lists, symbols
+// walked back-to-front in place (no intermediate symbol vector), binary-search decode, and N independent streams
+// (images x latent blocks) coded on N host threads.
+//
+// Bit-compatible with oracle/rans_oracle.c (the plain restatement of CompressAI's coder); checked in
+// tests/test_host_coder.py.
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/lvae_hip.h"
+
+namespace {
+constexpr uint32_t kPrecision = 16;
+constexpr uint32_t kBypassPrecision = 4;
+constexpr int32_t kMaxBypassVal = (1 << kBypassPrecision) - 1;
+constexpr uint64_t kRansL = 1ull << 31;
+
+struct BackWriter {
+    uint32_t* base;
+    uint32_t* ptr;
+    bool overflow = false;
+    inline void put(uint32_t w) {
+        if (ptr == base) { overflow = true; return; }
+        *--ptr = w;
+    }
+};
+
+inline void enc_put(uint64_t& x, BackWriter& w, uint32_t start, uint32_t freq) {
+    const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
+    if (x >= x_max) { w.put((uint32_t)x); x >>= 32; }
+    x = ((x / freq) << kPrecision) + (x % freq) + start;
+}
+inline void enc_put_bits(uint64_t& x, BackWriter& w, uint32_t val) {
+    const uint32_t freq = 1u << (16 - kBypassPrecision);
+    const uint64_t x_max = ((kRansL >> 16) << 32) * freq;
+    if (x >= x_max) { w.put((uint32_t)x); x >>= 32; }
+    x = (x << kBypassPrecision) | val;
+}
+inline uint32_t dec_get_bits(uint64_t& x, const uint32_t*& ptr, const uint32_t* end, bool& overrun) {
+    const uint32_t val = (uint32_t)(x & ((1u << kBypassPrecision) - 1));
+    x >>= kBypassPrecision;
+    if (x < kRansL) {
+        uint32_t w = 0;
+        if (ptr < end) w = *ptr; else overrun = true;
+        ++ptr;
+        x = (x << 32) | w;
+    }
+    return val;
+}
+}  // namespace
+
+extern "C" int lvae_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf) {
+    if (n <= 0 || precision <= 0 || precision > 16) return -22;
+    for (int i = 0; i < n; ++i)
+        if (pmf[i] < 0 || !std::isfinite(pmf[i])) return -1;
+    cdf[0] = 0;
+    const float scale = (float)(1 << precision);
+    for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)std::round(pmf[i] * scale);
+    uint32_t total = 0;
+    for (int i = 0; i <= n; ++i) total += cdf[i];
+    if (total == 0) return -2;
+    for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)((((uint64_t)1 << precision) * cdf[i]) / total);
+    for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];
+    cdf[n] = 1u << precision;
+    for (int i = 0; i < n; ++i) {
+        if (cdf[i] != cdf[i + 1]) continue;
+        uint32_t best_freq = ~0u;
+        int best = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t f = cdf[j + 1] - cdf[j];
+            if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+        }
+        if (best < 0) return -3;
+        if (best < i) for (int j = best + 1; j <= i; ++j) cdf[j]--;
+        else          for (int j = i + 1; j <= best; ++j) cdf[j]++;
+    }
+    return 0;
+}
+
+extern "C" int lvae_build_gaussian_tables(const float* scale_table, int n_scales, double multiplier, int cdf_form,
+                                          int32_t* qcdf, int row_stride, int32_t* cdf_len, int32_t* offset) {
+    if (n_scales <= 0) return -22;
+    int max_len = 0;
+    std::vector<int> centers(n_scales);
+    const float mult = (float)multiplier;   // torch: float32 tensor * python scalar -> float32 product
+    for (int i = 0; i < n_scales; ++i) {
+        centers[i] = (int)std::ceil(scale_table[i] * mult);
+        max_len = std::max(max_len, 2 * centers[i] + 1);
+    }
+    if (max_len + 2 > row_stride) return -2;
+    auto phi = [cdf_form](float v) -> float {
+        if (cdf_form == 0) return 0.5f * (1.0f + erff(v / (float)M_SQRT2));
+        return 0.5f * erfcf(-(float)M_SQRT1_2 * v);
+    };
+    std::vector<float> pmf(max_len + 1);
+    std::vector<uint32_t> cdf(max_len + 2);
+    for (int i = 0; i < n_scales; ++i) {
+        const int c = centers[i], len = 2 * c + 1;
+        const float s = scale_table[i];
+        float lower0 = 0.f;
+        for (int k = 0; k < len; ++k) {
+            const float a = (float)std::abs(k - c);
+            const float up = phi((0.5f - a) / s), lo = phi((-0.5f - a) / s);
+            pmf[k] = up - lo;
+            if (k == 0) lower0 = lo;
+        }
+        pmf[len] = 2.0f * lower0;
+        const int rc = lvae_pmf_to_quantized_cdf(pmf.data(), len + 1, 16, cdf.data());
+        if (rc) return rc;
+        int32_t* row = qcdf + (size_t)i * row_stride;
+        std::memset(row, 0, sizeof(int32_t) * row_stride);
+        for (int k = 0; k < len + 2; ++k) row[k] = (int32_t)cdf[k];
+        cdf_len[i] = len + 2;
+        offset[i] = -c;
+    }
+    return max_len + 2;
+}
+
+extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t* idx, size_t n,
+                                              const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                              const int32_t* offset, uint8_t* out, size_t out_cap) {
+    if (out_cap < 8) return -2;
+    // words are written backwards from the end of `out` (4-byte aligned view), then moved to the front
+    uint8_t* aligned = (uint8_t*)(((uintptr_t)out + 3) & ~(uintptr_t)3);
+    const size_t cap_words = (out_cap - (size_t)(aligned - out)) / 4;
+    BackWriter w{(uint32_t*)aligned, (uint32_t*)aligned + cap_words};
+    uint64_t x = kRansL;
+    for (size_t ii = n; ii-- > 0;) {
+        const int32_t row_i = idx[ii];
+        const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
+        const int32_t max_value = cdf_len[row_i] - 2;
+        if (max_value < 1) return -4;
+        int32_t value = sym[ii] - offset[row_i];
+        if (value >= 0 && value < max_value) {
+            enc_put(x, w, (uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]));
+            continue;
+        }
+        uint32_t raw;
+        if (value < 0) raw = (uint32_t)(-2 * (int64_t)value - 1);
+        else           raw = (uint32_t)(2 * ((int64_t)value - max_value));
+        int32_t n_bypass = 0;
+        while (n_bypass < 8 && (raw >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
+        // forward order is: [escape symbol][count nibbles: 15,15,..,rem][raw nibbles LSB first]; emit reversed
+        for (int32_t j = n_bypass - 1; j >= 0; --j) enc_put_bits(x, w, (raw >> (j * kBypassPrecision)) & kMaxBypassVal);
+        const int32_t n15 = n_bypass / kMaxBypassVal, rem = n_bypass % kMaxBypassVal;
+        enc_put_bits(x, w, (uint32_t)rem);
+        for (int32_t j = 0; j < n15; ++j) enc_put_bits(x, w, (uint32_t)kMaxBypassVal);
+        enc_put(x, w, (uint32_t)cdf[max_value], (uint32_t)(cdf[max_value + 1] - cdf[max_value]));
+    }
+    w.put((uint32_t)(x >> 32));
+    w.put((uint32_t)x);
+    if (w.overflow) return -2;
+    const size_t nbytes = (size_t)(((uint32_t*)aligned + cap_words) - w.ptr) * 4;
+    std::memmove(out, w.ptr, nbytes);
+    return (long)nbytes;
+}
+
+extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,
+                                             const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                             const int32_t* offset, int32_t* sym_out) {
+    if (in_len < 8 || (in_len & 3)) return -1;
+    std::vector<uint32_t> tmp;
+    const uint32_t* words;
+    if (((uintptr_t)in & 3) == 0) words = (const uint32_t*)in;
+    else { tmp.resize(in_len / 4); std::memcpy(tmp.data(), in, in_len); words = tmp.data(); }
+    const uint32_t* ptr = words;
+    const uint32_t* end = words + in_len / 4;
+    uint64_t x = (uint64_t)ptr[0] | ((uint64_t)ptr[1] << 32);
+    ptr += 2;
+    bool overrun = false;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t row_i = idx[i];
+        const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
+        const int32_t size = cdf_len[row_i];
+        const int32_t max_value = size - 2;
+        const uint32_t cf = (uint32_t)(x & 0xFFFF);
+        // largest s with cdf[s] <= cf  (cdf[0]=0, cdf[size-1]=65536 > cf)
+        int32_t lo = 0, hi = size - 1;
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)cdf[mid] <= cf) lo = mid; else hi = mid;
+        }
+        const int32_t s = lo;
+        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+        x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFF) - start;
+        if (x < kRansL) {
+            uint32_t wv = 0;
+            if (ptr < end) wv = *ptr; else overrun = true;
+            ++ptr;
+            x = (x << 32) | wv;
+        }
+        int32_t value = s;
+        if (value == max_value) {
+            int32_t val = (int32_t)dec_get_bits(x, ptr, end, overrun);
+            int32_t n_bypass = val;
+            while (val == kMaxBypassVal) {
+                val = (int32_t)dec_get_bits(x, ptr, end, overrun);
+                n_bypass += val;
+                if (overrun) return -3;
+            }
+            uint32_t raw = 0;
+            for (int32_t j = 0; j < n_bypass; ++j) {
+                val = (int32_t)dec_get_bits(x, ptr, end, overrun);
+                if (j < 8) raw |= (uint32_t)val << (j * kBypassPrecision);
+            }
+            value = (int32_t)(raw >> 1);
+            if (raw & 1) value = -value - 1;
+            else value += max_value;
+        }
+        sym_out[i] = value + offset[row_i];
+        if (overrun) return -3;
+    }
+    return 0;
+}
+
+namespace {
+template <class F>
+void parallel_for(int n, int n_threads, F&& f) {
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n) n_threads = n;
+    if (n_threads <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::vector<std::thread> th;
+    th.reserve(n_threads - 1);
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
+extern "C" int lvae_rans_encode_batch(int n_streams, const int32_t* const* sym, const uint8_t* const* idx,
+                                      const size_t* n, const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                      const int32_t* offset, uint8_t* const* out, const size_t* out_cap,
+                                      long* out_len, int n_threads) {
+    if (n_streams < 0) return -22;
+    parallel_for(n_streams, n_threads, [&](int s) {
+        out_len[s] = lvae_rans_encode_with_indexes(sym[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, out[s],
+                                                   out_cap[s]);
+    });
+    int rc = 0;
+    for (int s = 0; s < n_streams; ++s) if (out_len[s] < 0) rc = (int)out_len[s];
+    return rc;
+}
+
+extern "C" int lvae_rans_decode_batch(int n_streams, const uint8_t* const* in, const size_t* in_len,
+                                      const uint8_t* const* idx, const size_t* n, const int32_t* qcdf,
+                                      int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                      int32_t* const* sym_out, int* status, int n_threads) {
+    if (n_streams < 0) return -22;
+    parallel_for(n_streams, n_threads, [&](int s) {
+        status[s] = lvae_rans_decode_with_indexes(in[s], in_len[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset,
+                                                  sym_out[s]);
+    });
+    int rc = 0;
+    for (int s = 0; s < n_streams; ++s) if (status[s] < 0) rc = status[s];
+    return rc;
+}

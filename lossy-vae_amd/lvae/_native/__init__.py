@@ -1,0 +1,79 @@
+"""ctypes binding of liblvae_hip.so (C ABI: include/lvae_hip.h).
+
+The library is the product: if it is missing the package FAILS LOUDLY -- there is no PyTorch/CPU fallback for the
+encode/decode hot path.  Build it in-tree with `python lossy-vae_amd/build_native.py` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
+ABI_VERSION = 1
+_lib = None
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `lvae_gemm_desc` (include/lvae_hip.h)."""
+    _fields_ = [
+        ('A0', C.c_void_p), ('A1', C.c_void_p),
+        ('lda0', C.c_long), ('lda1', C.c_long),
+        ('K0', C.c_int), ('K1', C.c_int),
+        ('H', C.c_int), ('W', C.c_int),
+        ('Wt', C.c_void_p), ('ldw', C.c_long),
+        ('bias', C.c_void_p), ('gamma', C.c_void_p),
+        ('res', C.c_void_p), ('ldres', C.c_long),
+        ('out', C.c_void_p), ('ldo', C.c_long),
+        ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+        ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
+    ]
+
+
+A_PLAIN, A_PATCH2, A_CONV3 = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_GAMMA_RES, EPI_RES = 0, 1, 2, 3
+ST_ROWMAJOR, ST_SHUFFLE, ST_IMAGE = 0, 2, 3
+
+_vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+SIGNATURES = {
+    # name: (restype, argtypes)  -- one entry per symbol declared in include/lvae_hip.h
+    'lvae_abi_version': (_i, []),
+    'lvae_build_info': (C.c_char_p, []),
+    'lvae_pmf_to_quantized_cdf': (_i, [_vp, _i, _i, _vp]),
+    'lvae_build_gaussian_tables': (_i, [_vp, _i, _d, _i, _vp, _i, _vp, _vp]),
+    'lvae_rans_encode_with_indexes': (_l, [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz]),
+    'lvae_rans_decode_with_indexes': (_i, [_vp, _sz, _vp, _sz, _vp, _i, _vp, _vp, _vp]),
+    'lvae_rans_encode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i]),
+    'lvae_rans_decode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    'lvae_gemm_f32': (_i, [C.POINTER(GemmDesc), _vp]),
+    'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
+    'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),
+    'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+}
+
+
+def lib():
+    """Load (once) and return the native library; raises if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the HIP extension is the product path and there is no fallback. '
+                f'Build it with `python lossy-vae_amd/build_native.py` (hipcc --offload-arch=gfx950).')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        v = L.lvae_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f'liblvae_hip.so ABI {v} != expected {ABI_VERSION}; rebuild')
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed with code {rc} (hipError_t if > 0, argument error if < 0)')

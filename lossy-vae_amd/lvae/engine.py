@@ -1,0 +1,78 @@
+"""Launch plans: a model's encode/decode for one (batch, height, width) is recorded ONCE as a flat list of native
+launches (function pointer + fully resolved arguments: device addresses of pre-allocated NHWC buffers and packed
+weights), then replayed with a tight loop -- or as a HIP graph -- on the current HIP stream.
+
+This is the MI355X-side replacement for the reference's eager `nn.Module.forward` dispatch (~450 leaf modules and
+~10^3 elementwise kernels per encode: SURVEY.md 8(a) A15).  PyTorch is used only as the allocator / stream owner.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import GemmDesc
+
+
+class Plan:
+    def __init__(self, device):
+        self.lib = _native.lib()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('lvae hot path runs on an AMD GPU (torch device "cuda:N" under ROCm); there is no CPU '
+                               f'fallback (got device {self.device})')
+        self.ops = []          # [(fn, args, label)]
+        self.keep = []         # tensors / descs that must outlive the plan
+        self.bufs = {}
+        self.flops = 0
+        self.graph = None
+
+    # ---- memory
+    def buf(self, name, numel, dtype=torch.float32):
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            if t is not None:
+                self.keep.append(t)     # launches already recorded keep pointing at the old (smaller) scratch
+            t = torch.empty(int(numel), dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        return t
+
+    def new(self, numel, dtype=torch.float32):
+        t = torch.empty(int(numel), dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    # ---- recording
+    def add(self, fn, args, label=''):
+        self.ops.append((fn, tuple(args), label))
+
+    def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
+             gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
+             r=0, H=0, W=0, K=None, label='gemm'):
+        if K is None:
+            K = K0 + K1
+        d = GemmDesc()
+        d.A0, d.A1 = A0, A1
+        d.lda0, d.lda1 = (lda0 if lda0 is not None else K0), lda1
+        d.K0, d.K1, d.H, d.W = K0, K1, H, W
+        d.Wt, d.ldw = Wt, (ldw if ldw is not None else K)
+        d.bias, d.gamma, d.res, d.ldres = bias, gamma, res, ldres
+        d.out, d.ldo = out, (ldo if ldo is not None else N)
+        d.M, d.N, d.K = M, N, K
+        d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
+        self.keep.append(d)
+        self.flops += 2 * M * N * K
+        self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)
+
+    # ---- execution
+    def run(self, lo=0, hi=None, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        sp = ctypes.c_void_p(s)
+        for fn, args, label in self.ops[lo:hi]:
+            rc = fn(*args, sp)
+            if rc != 0:
+                raise RuntimeError(f'native launch "{label}" failed: rc={rc}')
+
+
+def ptr(t, offset_elems=0):
+    """Device address of a torch tensor (+ element offset)."""
+    return t.data_ptr() + offset_elems * t.element_size()

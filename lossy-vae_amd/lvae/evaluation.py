@@ -1,0 +1,101 @@
+"""Evaluation harness: drop-in for the reference's `imcoding_evaluate` (lvae/evaluation.py:15-67).
+
+Same contract: sorted rglob('*.*') over the dataset folder; per image compress_file -> file size*8 ->
+decompress_file; PSNR on the un-rounded float reconstruction; bpp over the ORIGINAL pixel count; mean of per-image
+values.  `imcoding_evaluate_sharded` is the multi-GPU form (one process per GPU, images rank::world, one tiny
+all_gather of per-image stats over RCCL/xGMI) -- the only collective on this path.
+"""
+import math
+from collections import defaultdict
+from pathlib import Path
+from tempfile import gettempdir
+
+import torch
+
+from .paths import known_datasets
+from .utils.coding import pil_to_tensor01
+
+
+def _list_images(dataset):
+    root = known_datasets.get(dataset, Path(dataset))
+    img_paths = list(Path(root).rglob('*.*'))
+    img_paths.sort()
+    return img_paths
+
+
+def _eval_one(model, impath, tmp_bits_dir, tag=''):
+    from PIL import Image
+    tmp_bits_path = tmp_bits_dir / f'{impath.stem}{tag}.bits'
+    model.compress_file(impath, tmp_bits_path)
+    num_bits = tmp_bits_path.stat().st_size * 8
+    fake = model.decompress_file(tmp_bits_path).squeeze(0).cpu()
+    tmp_bits_path.unlink()
+    real = pil_to_tensor01(Image.open(impath))
+    mse = (real - fake).square().mean().item()
+    return {'bpp': float(num_bits / float(real.shape[1] * real.shape[2])), 'mse': float(mse),
+            'psnr': float(-10 * math.log10(mse))}
+
+
+@torch.no_grad()
+def imcoding_evaluate(model, dataset, progress=False):
+    """dict {bpp, mse, psnr}: dataset means of per-image values (evaluation.py:59-66)."""
+    assert hasattr(model, 'compress_file') and hasattr(model, 'decompress_file')
+    img_paths = _list_images(dataset)
+    tmp_bits_dir = Path(gettempdir())
+    sums, n = defaultdict(float), 0
+    it = img_paths
+    if progress:
+        from tqdm import tqdm
+        it = tqdm(img_paths, ascii=True)
+    for impath in it:
+        stats = _eval_one(model, impath, tmp_bits_dir)
+        n += 1
+        for k, v in stats.items():      # timm AverageMeter: running sum / count
+            sums[k] += v
+    return {k: v / n for k, v in sums.items()}
+
+
+def shard_paths(img_paths, rank, world):
+    """Rank r of W codes sorted(img_paths)[r::W]."""
+    return img_paths[rank::world]
+
+
+def gather_stats(local, world, device=None):
+    """all_gather of per-image (index, bpp, mse, psnr) rows as float64; returns rows sorted by image index so that the
+    mean is computed in exactly the single-process order."""
+    import torch.distributed as dist
+    t = torch.tensor(local, dtype=torch.float64).reshape(-1, 4)
+    if device is not None:
+        t = t.to(device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
+    mx = max(int(c.item()) for c in counts)
+    pad = torch.zeros(mx, 4, dtype=torch.float64, device=t.device)
+    pad[:t.shape[0]] = t
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    rows = torch.cat([b[:int(c.item())] for b, c in zip(bufs, counts)], 0).cpu()
+    return rows[torch.argsort(rows[:, 0])]
+
+
+@torch.no_grad()
+def imcoding_evaluate_sharded(model, dataset):
+    """Same result as imcoding_evaluate, with the image list sharded over torch.distributed ranks."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    img_paths = _list_images(dataset)
+    tmp_bits_dir = Path(gettempdir())
+    local = []
+    for idx in range(rank, len(img_paths), world):
+        s = _eval_one(model, img_paths[idx], tmp_bits_dir, tag=f'.r{rank}')
+        local.append([float(idx), s['bpp'], s['mse'], s['psnr']])
+    dev = next(model.parameters()).device
+    rows = gather_stats(local, world, dev if dist.get_backend() == 'nccl' else None)
+    assert rows.shape[0] == len(img_paths)
+    out = {}
+    for j, k in enumerate(('bpp', 'mse', 'psnr')):
+        acc = 0.0
+        for v in rows[:, j + 1].tolist():
+            acc += v
+        out[k] = acc / rows.shape[0]
+    return out

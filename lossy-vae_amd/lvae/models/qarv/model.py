@@ -1,0 +1,604 @@
+"""QARV (variable-rate hierarchical VAE) inference codec on MI355X.
+
+API surface of the reference's `VariableRateLossyVAE` (lvae/models/qarv/model.py:169-581) for the encode/decode
+path: `compress_mode`, `compress`, `decompress`, `compress_file`, `decompress_file`, `default_lmb`, `lmb_range`,
+`max_stride`, `num_latents`, nn.Module behaviour (`.to`, `.eval`, `.parameters`, `load_state_dict` with the
+reference's key names).  Bitstreams use the reference's container (qarv/model.py:525-528,567).
+
+Nothing here calls a PyTorch compute kernel on the hot path: the module tree below only OWNS parameters under the
+reference's names; `_prepare()` repacks them once into NHWC/GEMM-friendly device arrays and `_EncPlan`/`_DecPlan`
+record the whole network as native HIP launches (lvae/engine.py).  Extension over the reference: `compress_batch` /
+`decompress_batch` code B images per call (reference: batch 1 only, model.py:521) -- the GPU part runs batched, the
+rANS streams of the B images x 9 latent blocks are coded by parallel host threads.
+"""
+import math
+import struct
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _native
+from ...engine import Plan, ptr
+from ...utils import coding
+from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
+
+EMBED_DIM = 256
+
+
+# ----------------------------------------------------------------------------------------------- parameter holders
+class _Marker(nn.Module):
+    """Parameter-less placeholder keeping list indices aligned with the reference (SetKey / CompresionStopFlag,
+    lvae/models/common.py:48-66)."""
+    def __init__(self, kind, key=None):
+        super().__init__()
+        self.kind, self.key = kind, key
+
+
+class _MlpParams(nn.Module):
+    def __init__(self, dim, hidden, out_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, out_dim)
+
+
+class CNXParams(nn.Module):
+    """Parameters of one ConvNeXtBlockAdaLN (lvae/models/common.py:110-140): conv_dw, embedding_layer.1, mlp.fc1/fc2,
+    gamma (1,C,1,1) initialised to 1e-6."""
+    kind = 'cnx'
+
+    def __init__(self, dim, kernel_size=7, mlp_ratio=2, embed_dim=EMBED_DIM):
+        super().__init__()
+        self.dim, self.kernel_size, self.hidden = dim, kernel_size, int(mlp_ratio * dim)
+        self.conv_dw = nn.Conv2d(dim, dim, kernel_size=kernel_size, padding=(kernel_size - 1) // 2, groups=dim)
+        self.embedding_layer = nn.Sequential(nn.Identity(), nn.Linear(embed_dim, 2 * dim), nn.Identity())
+        self.mlp = _MlpParams(dim, self.hidden, dim)
+        self.gamma = nn.Parameter(torch.full(size=(1, dim, 1, 1), fill_value=1e-6))
+
+
+def _conv(cin, cout, k, stride=1, padding=0):
+    c = nn.Conv2d(cin, cout, k, stride, padding)
+    c.bias.data.mul_(0.0)          # get_conv(zero_bias=True), common.py:8-14
+    return c
+
+
+class DownParams(nn.Conv2d):
+    """patch_downsample (common.py:29-30): conv kernel=stride=rate."""
+    kind = 'down'
+
+    def __init__(self, cin, cout, rate):
+        super().__init__(cin, cout, rate, rate, 0)
+        self.bias.data.mul_(0.0)
+        self.rate = rate
+
+
+class UpParams(nn.Sequential):
+    """patch_upsample (common.py:33-38): conv1x1 to cout*rate^2 channels + PixelShuffle(rate)."""
+    kind = 'up'
+
+    def __init__(self, cin, cout, rate):
+        super().__init__(_conv(cin, cout * rate * rate, 1), nn.Identity())
+        self.cin, self.cout, self.rate = cin, cout, rate
+
+
+class VRLVParams(nn.Module):
+    """Parameters of one VRLVBlockBase (qarv/model.py:19-42)."""
+    kind = 'vrlv'
+
+    def __init__(self, width, zdim, enc_key, enc_width, kernel_size=7, mlp_ratio=2):
+        super().__init__()
+        self.width, self.zdim, self.enc_key, self.enc_width, self.kernel_size = width, zdim, enc_key, enc_width, kernel_size
+        self.resnet_front = CNXParams(width, kernel_size, mlp_ratio)
+        self.resnet_end = CNXParams(width, kernel_size, mlp_ratio)
+        self.posterior0 = CNXParams(enc_width, kernel_size)
+        self.posterior1 = CNXParams(width, kernel_size)
+        self.posterior2 = CNXParams(width, kernel_size)
+        self.post_merge = _conv(width + enc_width, width, 1)
+        self.posterior = _conv(width, zdim, 3, 1, 1)
+        self.z_proj = _conv(zdim, width, 1)
+        self.prior = _conv(width, zdim * 2, 1)
+        self.discrete_gaussian = DiscretizedGaussian(cdf_form='erf')
+        self.is_latent_block = True
+
+
+class _Encoder(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        self.enc_blocks = nn.ModuleList(blocks)
+
+
+# ----------------------------------------------------------------------------------------------- launch plans
+class _Packed:
+    """Device-resident, kernel-friendly copies of the weights (built once per device / weight version)."""
+
+    def __init__(self, model, device):
+        self.t = {}
+        self.adaln_off = {}
+        dev = device
+        f32 = dict(device=dev, dtype=torch.float32)
+        ws, bs = [], []
+        total = 0
+
+        def put(name, t):
+            self.t[name] = t.detach().to(**f32).contiguous()
+
+        def cnx(p, m):
+            nonlocal total
+            C, k = m.dim, m.kernel_size
+            put(p + '.dw_w', m.conv_dw.weight.reshape(C, k * k).t())            # [k*k][C]
+            put(p + '.dw_b', m.conv_dw.bias)
+            put(p + '.fc1_w', m.mlp.fc1.weight); put(p + '.fc1_b', m.mlp.fc1.bias)
+            put(p + '.fc2_w', m.mlp.fc2.weight); put(p + '.fc2_b', m.mlp.fc2.bias)
+            put(p + '.gamma', m.gamma.reshape(C))
+            lin = m.embedding_layer[1]
+            b = lin.bias.detach().clone().float()
+            b[C:] += 1.0                       # second half is `scale`; the kernel consumes (1 + scale) (common.py:151-152)
+            ws.append(lin.weight.detach().float()); bs.append(b)
+            self.adaln_off[p] = total
+            total += 2 * C
+
+        for i, m in enumerate(model.encoder.enc_blocks):
+            p = f'encoder.enc_blocks.{i}'
+            if m.kind == 'cnx':
+                cnx(p, m)
+            elif m.kind == 'down' and m.rate == 4:
+                put(p + '.w', m.weight.reshape(m.out_channels, -1).t())           # [48][Cout], k=(ci*4+i)*4+j
+                put(p + '.b', m.bias)
+            elif m.kind == 'down':
+                put(p + '.w', m.weight.permute(0, 2, 3, 1).reshape(m.out_channels, -1))   # [Cout][(i,j,ci)]
+                put(p + '.b', m.bias)
+        for i, m in enumerate(model.dec_blocks):
+            p = f'dec_blocks.{i}'
+            if m.kind == 'cnx':
+                cnx(p, m)
+            elif m.kind == 'up':
+                w = m[0].weight.reshape(m.cout * m.rate ** 2, m.cin)
+                b = m[0].bias
+                if m.cout > 3:      # NHWC pixel-shuffle store wants columns ordered (i, j, c)
+                    r2 = m.rate ** 2
+                    w = w.reshape(m.cout, r2, m.cin).permute(1, 0, 2).reshape(r2 * m.cout, m.cin)
+                    b = b.reshape(m.cout, r2).t().reshape(-1)
+                put(p + '.w', w); put(p + '.b', b)
+            elif m.kind == 'vrlv':
+                for sub in ('resnet_front', 'resnet_end', 'posterior0', 'posterior1', 'posterior2'):
+                    cnx(f'{p}.{sub}', getattr(m, sub))
+                put(p + '.post_merge.w', m.post_merge.weight.reshape(m.width, -1)); put(p + '.post_merge.b', m.post_merge.bias)
+                put(p + '.posterior.w', m.posterior.weight.permute(0, 2, 3, 1).reshape(m.zdim, -1))
+                put(p + '.posterior.b', m.posterior.bias)
+                put(p + '.z_proj.w', m.z_proj.weight.reshape(m.width, m.zdim)); put(p + '.z_proj.b', m.z_proj.bias)
+                put(p + '.prior.w', m.prior.weight.reshape(2 * m.zdim, m.width)); put(p + '.prior.b', m.prior.bias)
+        put('bias', model.bias.reshape(-1))
+        put('lmb.0.w', model.lmb_embedding[0].weight); put('lmb.0.b', model.lmb_embedding[0].bias)
+        put('lmb.2.w', model.lmb_embedding[2].weight); put('lmb.2.b', model.lmb_embedding[2].bias)
+        put('adaln.w', torch.cat(ws, 0)); put('adaln.b', torch.cat(bs, 0))
+        self.adaln_total = total
+        self.adaln = torch.zeros(total, **f32)          # per-lambda (shift | 1+scale) vectors of all blocks
+        self.emb_in = torch.zeros(EMBED_DIM, **f32)
+        self.emb_h = torch.zeros(EMBED_DIM, **f32)
+        self.emb = torch.zeros(EMBED_DIM, **f32)
+        self.scale_table = model._dg().scale_table.detach().to(**f32).contiguous()
+        self.scale_bound = float(model._dg().lower_bound_scale.bound.item())
+
+    def p(self, name):
+        return self.t[name].data_ptr()
+
+
+class _NetPlan(Plan):
+    """Shared recording helpers for the encode and decode plans."""
+
+    def __init__(self, model, pk, B):
+        super().__init__(pk.adaln.device)
+        self.model, self.pk, self.B = model, pk, B
+        self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
+        self.lat_shapes = []                    # (z, HW)
+
+    def scratch(self, M, C, hid):
+        y = self.buf('y', M * C)
+        h = self.buf('hid', M * hid)
+        return y, h
+
+    def cnx(self, p, m, x, out, H, W):
+        """ConvNeXtBlockAdaLN (common.py:142-161) = dwconv+LN+AdaLN kernel, fc1+GELU GEMM, fc2+gamma+residual GEMM."""
+        pk, lib = self.pk, self.lib
+        C, k, hid = m.dim, m.kernel_size, m.hidden
+        M = self.B * H * W
+        y, h = self.scratch(M, C, hid)
+        off = pk.adaln_off[p]
+        self.add(lib.lvae_dwconv_ln_f32, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
+                                          ptr(pk.adaln, off + C), y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
+        self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=h.data_ptr(),
+                  epi=_native.EPI_BIAS_GELU, label=p + '.fc1')
+        self.gemm(A0=h.data_ptr(), K0=hid, M=M, N=C, Wt=pk.p(p + '.fc2_w'), bias=pk.p(p + '.fc2_b'),
+                  gamma=pk.p(p + '.gamma'), res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, label=p + '.fc2')
+
+    def upsample(self, p, m, x, out, H, W):
+        pk = self.pk
+        M = self.B * H * W
+        final = m.cout <= 3
+        self.gemm(A0=x, K0=m.cin, M=M, N=m.cout * m.rate ** 2, Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'), out=out,
+                  store=_native.ST_IMAGE if final else _native.ST_SHUFFLE, r=m.rate, H=H, W=W, label=p + '.up')
+
+    def prior(self, p, m, f, H, W):
+        """transform_prior (qarv/model.py:44-54) + build_indexes (:106/:112). Returns pm buffer."""
+        pk, lib, B = self.pk, self.lib, self.B
+        M, z = B * H * W, m.zdim
+        self.cnx(p + '.resnet_front', m.resnet_front, f, f, H, W)
+        prm = self.buf('prm', M * 2 * z)
+        self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
+                  out=prm.data_ptr(), label=p + '.prior')
+        pm = self.new(M * z)
+        ioff = sum(s[0] * s[1] for s in self.lat_shapes) * B
+        self.lat_shapes.append((z, H * W))
+        self.idx_off.append(ioff)
+        self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
+                                            pk.scale_table.numel(), pk.scale_bound, B, H * W, z), p + '.prior_index')
+        return pm, ioff
+
+    def fuse_and_end(self, p, m, f, zhat, H, W):
+        """fuse_feature_and_z + resnet_end (qarv/model.py:72-75,117-118)."""
+        pk = self.pk
+        M = self.B * H * W
+        self.gemm(A0=zhat, K0=m.zdim, M=M, N=m.width, Wt=pk.p(p + '.z_proj.w'), bias=pk.p(p + '.z_proj.b'), res=f,
+                  ldres=m.width, out=f, epi=_native.EPI_RES, label=p + '.z_proj')
+        self.cnx(p + '.resnet_end', m.resnet_end, f, f, H, W)
+
+    def alloc_latent_io(self, nH, nW):
+        B = self.B
+        total, s = 0, 1
+        # latent resolution per block follows the top-down path: starts at (nH,nW), doubles at each upsample
+        for m in self.model.dec_blocks:
+            if m.kind == 'vrlv':
+                total += m.zdim * nH * s * nW * s
+            elif m.kind == 'up':
+                s *= m.rate
+            elif m.kind == 'stop':
+                break
+        self.n_sym = total * B
+        self.sym_all = self.new(self.n_sym, torch.int32)
+        self.idx_all = self.new(self.n_sym, torch.uint8)
+        self.sym_host = torch.empty(self.n_sym, dtype=torch.int32).pin_memory()
+        self.idx_host = torch.empty(self.n_sym, dtype=torch.uint8).pin_memory()
+        self.sym_np, self.idx_np = self.sym_host.numpy(), self.idx_host.numpy()
+
+
+class _EncPlan(_NetPlan):
+    """forward_end2end(mode='compress') (qarv/model.py:294-315) for B images of size HxW."""
+
+    def __init__(self, model, pk, B, H, W):
+        super().__init__(model, pk, B)
+        lib = self.lib
+        self.im = self.new(B * 3 * H * W)
+        self.alloc_latent_io(H // 64, W // 64)
+        feats = {}
+        tapped = set()
+        h, w = H, W
+        x = None
+        for i, m in enumerate(model.encoder.enc_blocks):
+            p = f'encoder.enc_blocks.{i}'
+            if m.kind == 'down' and m.rate == 4:
+                h, w = h // 4, w // 4
+                x = self.new(B * h * w * m.out_channels)
+                self.add(lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
+                                             m.out_channels, model.im_shift, model.im_scale), p + '.stem')
+                self.flops += 2 * B * h * w * m.out_channels * 48
+            elif m.kind == 'down':
+                h, w = h // 2, w // 2
+                nx = self.new(B * h * w * m.out_channels)
+                self.gemm(A0=x.data_ptr(), K0=m.in_channels, M=B * h * w, N=m.out_channels, K=4 * m.in_channels,
+                          Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'), out=nx.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w,
+                          label=p + '.down')
+                x = nx
+            elif m.kind == 'cnx':
+                if x.data_ptr() in tapped:               # feature was tapped by SetKey: keep it, write elsewhere
+                    nx = self.new(x.numel())
+                    self.cnx(p, m, x.data_ptr(), nx.data_ptr(), h, w)
+                    x = nx
+                else:
+                    self.cnx(p, m, x.data_ptr(), x.data_ptr(), h, w)
+            elif m.kind == 'key':
+                feats[m.key] = (x, h, w)
+                tapped.add(x.data_ptr())
+        # top-down path
+        h, w = H // 64, W // 64
+        width = model.dec_blocks[0].width
+        f = self.new(B * h * w * width)
+        self.add(lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
+        for i, m in enumerate(model.dec_blocks):
+            p = f'dec_blocks.{i}'
+            if m.kind == 'vrlv':
+                M, z = B * h * w, m.zdim
+                pm, ioff = self.prior(p, m, f.data_ptr(), h, w)
+                ef, eh, ew = feats[m.enc_key]
+                assert (eh, ew) == (h, w)
+                e = self.buf('post_e', M * m.enc_width)
+                g = self.buf('post_g', M * m.width)
+                mg = self.buf('post_m', M * m.width)
+                self.cnx(p + '.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), h, w)
+                self.cnx(p + '.posterior1', m.posterior1, f.data_ptr(), g.data_ptr(), h, w)
+                self.gemm(A0=g.data_ptr(), K0=m.width, A1=e.data_ptr(), K1=m.enc_width, lda1=m.enc_width, M=M, N=m.width,
+                          Wt=pk.p(p + '.post_merge.w'), bias=pk.p(p + '.post_merge.b'), out=mg.data_ptr(),
+                          label=p + '.post_merge')
+                self.cnx(p + '.posterior2', m.posterior2, mg.data_ptr(), mg.data_ptr(), h, w)
+                qm = self.buf('qm', M * z)
+                self.gemm(A0=mg.data_ptr(), K0=m.width, M=M, N=z, K=9 * m.width, Wt=pk.p(p + '.posterior.w'),
+                          bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w,
+                          label=p + '.posterior')
+                zhat = self.buf('zhat', M * z)
+                self.sym_off.append(ioff)
+                self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
+                                                 B, h * w, z), p + '.quantize')
+                self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
+            elif m.kind == 'cnx':
+                self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
+            elif m.kind == 'up':
+                nf = self.new(B * h * w * m.rate ** 2 * m.cout)
+                self.upsample(p, m, f.data_ptr(), nf.data_ptr(), h, w)
+                f = nf
+                h, w = h * m.rate, w * m.rate
+            elif m.kind == 'stop':
+                break                                                     # qarv/model.py:310-312
+
+
+class _DecPlan(_NetPlan):
+    """decompress() (qarv/model.py:531-557): 9 GPU segments separated by host rANS decodes."""
+
+    def __init__(self, model, pk, B, nH, nW):
+        super().__init__(model, pk, B)
+        lib = self.lib
+        self.alloc_latent_io_full(nH, nW)
+        h, w = nH, nW
+        width = model.dec_blocks[0].width
+        f = self.new(B * h * w * width)
+        self.add(lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
+        self.cuts = []        # op index after each prior_index (host decode happens there)
+        self.out = None
+        for i, m in enumerate(model.dec_blocks):
+            p = f'dec_blocks.{i}'
+            if m.kind == 'vrlv':
+                M, z = B * h * w, m.zdim
+                pm, ioff = self.prior(p, m, f.data_ptr(), h, w)
+                self.cuts.append(len(self.ops))
+                self.sym_off.append(ioff)
+                zhat = self.buf('zhat', M * z)
+                self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z),
+                         p + '.dequantize')
+                self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
+            elif m.kind == 'cnx':
+                self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
+            elif m.kind == 'up':
+                final = m.cout <= 3
+                nf = self.new(B * h * w * m.rate ** 2 * m.cout)
+                self.upsample(p, m, f.data_ptr(), nf.data_ptr(), h, w)
+                f = nf
+                h, w = h * m.rate, w * m.rate
+                if final:
+                    self.out = nf.view(B, m.cout, h, w)
+        assert self.out is not None
+
+    def alloc_latent_io_full(self, nH, nW):
+        self.alloc_latent_io(nH, nW)
+
+
+# ----------------------------------------------------------------------------------------------- the model
+class VariableRateLossyVAE(nn.Module):
+    log2_e = math.log2(math.e)
+    MAX_LMB = 8192
+
+    def __init__(self, config: dict):
+        super().__init__()
+        self.encoder = _Encoder(config.pop('enc_blocks'))
+        self.dec_blocks = nn.ModuleList(config.pop('dec_blocks'))
+        width = self.dec_blocks[0].width
+        self.bias = nn.Parameter(torch.zeros(1, width, 1, 1))
+        self.num_latents = len([b for b in self.dec_blocks if getattr(b, 'is_latent_block', False)])
+
+        _low, _high = config['lmb_range']
+        self.lmb_range = (float(_low), float(_high))
+        self.default_lmb = self.lmb_range[1]
+        self.lmb_embed_dim = config['lmb_embed_dim']
+        self.lmb_embedding = nn.Sequential(
+            nn.Linear(self.lmb_embed_dim[0], self.lmb_embed_dim[1]), nn.GELU(),
+            nn.Linear(self.lmb_embed_dim[1], self.lmb_embed_dim[1]))
+        self._sin_period = config['sin_period']
+
+        self.im_shift = float(config['im_shift'])
+        self.im_scale = float(config['im_scale'])
+        self.max_stride = config['max_stride']
+        self.register_buffer('_dummy', torch.zeros(1), persistent=False)
+        self.compressing = False
+        self.coder_threads = 0          # 0 = all hardware threads
+        self._packed = None
+        self._packed_key = None
+        self._plans = {}
+        self._cur_lmb = None
+
+    # ---- helpers
+    def _dg(self) -> DiscretizedGaussian:
+        for b in self.dec_blocks:
+            if getattr(b, 'is_latent_block', False):
+                return b.discrete_gaussian
+        raise RuntimeError('no latent block')
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def _invalidate(self):
+        self._packed, self._plans, self._cur_lmb = None, {}, None
+
+    def _prepare(self):
+        dev = self._dummy.device
+        if self._packed is None or self._packed.adaln.device != dev:
+            if dev.type != 'cuda':
+                raise RuntimeError('lvae (MI355X build): compress/decompress run on the GPU only; move the model with '
+                                   '.to("cuda") -- there is deliberately no CPU fallback')
+            _native.lib()
+            with torch.no_grad():
+                self._packed = _Packed(self, dev)
+            self._plans, self._cur_lmb = {}, None
+        return self._packed
+
+    def _set_lmb(self, lmb):
+        """_get_lmb_embedding (qarv/model.py:266-287) + every block's AdaLN embedding_layer (common.py:150-151), once
+        per lambda: sinusoidal features on the host (128 cos + 128 sin), then three GEMV launches."""
+        pk = self._prepare()
+        lmb = float(np.float32(lmb))
+        if self._cur_lmb == lmb:
+            return
+        s = np.log(np.float32(lmb)) * np.float32(self._sin_period) / np.float32(math.log(self.MAX_LMB))
+        dim = self.lmb_embed_dim[0]
+        expo = np.linspace(0, 1, dim // 2, dtype=np.float32)
+        freqs = np.power(np.float32(self._sin_period), -expo).astype(np.float32)
+        args = (np.float32(s) * freqs).astype(np.float32)
+        e = np.concatenate([np.cos(args), np.sin(args)]).astype(np.float32)
+        pk.emb_in.copy_(torch.from_numpy(e))
+        lib = _native.lib()
+        st = torch.cuda.current_stream(pk.adaln.device).cuda_stream
+        _native.check(lib.lvae_gemv_f32(pk.p('lmb.0.w'), pk.p('lmb.0.b'), pk.emb_in.data_ptr(), pk.emb_h.data_ptr(),
+                                        self.lmb_embed_dim[1], dim, 0, 1, st), 'gemv lmb.0')
+        _native.check(lib.lvae_gemv_f32(pk.p('lmb.2.w'), pk.p('lmb.2.b'), pk.emb_h.data_ptr(), pk.emb.data_ptr(),
+                                        self.lmb_embed_dim[1], self.lmb_embed_dim[1], 0, 0, st), 'gemv lmb.2')
+        _native.check(lib.lvae_gemv_f32(pk.p('adaln.w'), pk.p('adaln.b'), pk.emb.data_ptr(), pk.adaln.data_ptr(),
+                                        pk.adaln_total, self.lmb_embed_dim[1], 1, 0, st), 'gemv adaln')
+        self._cur_lmb = lmb
+
+    def _plan(self, kind, B, a, b):
+        key = (kind, B, a, b)
+        pl = self._plans.get(key)
+        if pl is None:
+            pk = self._prepare()
+            pl = _EncPlan(self, pk, B, a, b) if kind == 'enc' else _DecPlan(self, pk, B, a, b)
+            self._plans[key] = pl
+        return pl
+
+    # ---- reference API
+    def compress_mode(self, mode=True):
+        """qarv/model.py:509-514: (re)build the CDF tables of every latent block."""
+        if mode:
+            first = None
+            for block in self.dec_blocks:
+                if getattr(block, 'is_latent_block', False):
+                    dg = block.discrete_gaussian
+                    if first is None:
+                        dg.update()
+                        first = dg
+                    else:       # all blocks share one scale table: identical rows, build once
+                        dg._quantized_cdf, dg._offset, dg._cdf_length = first._quantized_cdf, first._offset, first._cdf_length
+                        dg._host = None
+        self.compressing = mode
+
+    @torch.no_grad()
+    def compress_batch(self, im, lmb=None):
+        """Encode a (B,3,H,W) batch -> list of B byte strings (each identical to `compress(im[b:b+1])`)."""
+        lmb = lmb or self.default_lmb
+        assert im.dim() == 4 and im.shape[1] == 3 and not im.requires_grad
+        B, _, H, W = im.shape
+        assert (H % self.max_stride == 0) and (W % self.max_stride == 0), f'{im.shape=}'
+        self._prepare()
+        self._set_lmb(lmb)
+        pl = self._plan('enc', B, H, W)
+        pl.im.view(B, 3, H, W).copy_(im)
+        pl.run()
+        pl.sym_host.copy_(pl.sym_all, non_blocking=True)
+        pl.idx_host.copy_(pl.idx_all, non_blocking=True)
+        torch.cuda.current_stream(pl.device).synchronize()
+        tables = self._dg().host_tables()
+        sv, iv = [], []
+        for b in range(B):
+            for li, (z, hw) in enumerate(pl.lat_shapes):
+                o = pl.sym_off[li] + b * z * hw
+                sv.append(pl.sym_np[o:o + z * hw]); iv.append(pl.idx_np[o:o + z * hw])
+        strings = rans_encode_streams(tables, sv, iv, self.coder_threads)
+        nl = len(pl.lat_shapes)
+        assert nl == self.num_latents
+        out = []
+        header = struct.pack('f', lmb) + struct.pack('3H', 1, H // self.max_stride, W // self.max_stride)
+        for b in range(B):
+            out.append(header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]))
+        return out
+
+    @torch.no_grad()
+    def compress(self, im, lmb=None):
+        """qarv/model.py:516-529 (single image)."""
+        assert im.shape[0] == 1, f'Right now only support a single image, got {im.shape=}'
+        return self.compress_batch(im, lmb)[0]
+
+    @torch.no_grad()
+    def decompress_batch(self, strings):
+        """Decode a list of byte strings that share lambda and latent shape -> (B,3,H,W) tensor in [0,1]."""
+        B = len(strings)
+        heads = [struct.unpack('f', s[:4]) + struct.unpack('3H', s[4:10]) for s in strings]
+        lmb, nB, nH, nW = heads[0]
+        assert nB == 1 and all(h == heads[0] for h in heads), 'batch must share lambda and shape'
+        lv = [coding.unpack_byte_string(s[10:]) for s in strings]
+        self._prepare()
+        self._set_lmb(lmb)
+        pl = self._plan('dec', B, nH, nW)
+        assert all(len(x) == len(pl.cuts) for x in lv), f'expected {len(pl.cuts)} strings per image'
+        tables = self._dg().host_tables()
+        stream = torch.cuda.current_stream(pl.device)
+        lo = 0
+        for li, cut in enumerate(pl.cuts):
+            pl.run(lo, cut)
+            lo = cut
+            z, hw = pl.lat_shapes[li]
+            o, n = pl.idx_off[li], B * z * hw
+            pl.idx_host[o:o + n].copy_(pl.idx_all[o:o + n], non_blocking=True)
+            stream.synchronize()
+            iv = [pl.idx_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(B)]
+            sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(B)]
+            rans_decode_streams(tables, [lv[b][li] for b in range(B)], iv, sv, self.coder_threads)
+            pl.sym_all[o:o + n].copy_(pl.sym_host[o:o + n], non_blocking=True)
+        pl.run(lo, None)
+        return pl.out.clone()
+
+    @torch.no_grad()
+    def decompress(self, string):
+        """qarv/model.py:531-557."""
+        return self.decompress_batch([string])
+
+    @torch.no_grad()
+    def compress_file(self, img_path, output_path, lmb=None):
+        """qarv/model.py:559-570."""
+        from PIL import Image
+        img = Image.open(img_path)
+        img_padded = coding.pad_divisible_by(img, div=self.max_stride)
+        im = coding.pil_to_tensor01(img_padded).unsqueeze_(0).to(device=self._dummy.device)
+        body_str = self.compress(im, lmb=lmb)
+        header_str = struct.pack('2H', img.height, img.width)
+        with open(output_path, 'wb') as f:
+            f.write(header_str + body_str)
+
+    @torch.no_grad()
+    def decompress_file(self, bits_path):
+        """qarv/model.py:572-581."""
+        with open(bits_path, 'rb') as f:
+            header_str = f.read(4)
+            body_str = f.read()
+        img_h, img_w = struct.unpack('2H', header_str)
+        im_hat = self.decompress(body_str)
+        return im_hat[:, :, :img_h, :img_w]
+
+    # ---- debugging / test access (not on the hot path)
+    @torch.no_grad()
+    def encode_trace(self, im, lmb=None):
+        """Run the encode plan and return per-block int arrays (symbols, indexes in NCHW order) for parity tests."""
+        lmb = lmb or self.default_lmb
+        B, _, H, W = im.shape
+        self._prepare(); self._set_lmb(lmb)
+        pl = self._plan('enc', B, H, W)
+        pl.im.view(B, 3, H, W).copy_(im)
+        pl.run()
+        torch.cuda.current_stream(pl.device).synchronize()
+        sym, idx = pl.sym_all.cpu().numpy(), pl.idx_all.cpu().numpy()
+        out = []
+        h, w = H // 64, W // 64
+        for li, (z, hw) in enumerate(pl.lat_shapes):
+            o = pl.sym_off[li]
+            out.append(dict(symbols=sym[o:o + B * z * hw].reshape(B, z, hw).copy(),
+                            indexes=idx[o:o + B * z * hw].reshape(B, z, hw).copy()))
+        return out

@@ -33,3 +33,28 @@ def qarv_seeded_sd():
     from oracle import qarv_oracle
     arch = qarv_oracle.qarv_base_arch()
     return seeded_init.seeded_state_dict(qarv_oracle.qarv_param_shapes(arch), seed=0)
+
+
+def load_seeded_into(model, sd_np):
+    """Load seeded numpy weights (reference key names) into a product model, keeping its own buffers."""
+    import torch
+    full = model.state_dict()
+    for k, v in sd_np.items():
+        assert k in full and tuple(full[k].shape) == tuple(v.shape), k
+        full[k] = torch.from_numpy(v)
+    model.load_state_dict(full)
+    return model
+
+
+@pytest.fixture(scope='session')
+def product_model(qarv_seeded_sd):
+    """qarv_base on cuda:0 with the seeded weights, in compress mode (HIP path)."""
+    import torch
+    import lvae
+    assert torch.cuda.is_available()
+    m = lvae.get_model('qarv_base')
+    load_seeded_into(m, qarv_seeded_sd)
+    m = m.to('cuda:0')
+    m.eval()
+    m.compress_mode()
+    return m

@@ -1,0 +1,274 @@
+"""-m gpu: each HIP kernel (called through the C ABI via ctypes) against a plain PyTorch fp32 reference of the same op.
+
+Tolerances: fp32 MFMA accumulation is an fmaf chain in a fixed k-order; torch sums in another order, so outputs agree
+to ~1e-6 relative of sum|a*b| -- asserted as 2e-5 abs on O(1) data (the north-star tolerance is 1e-4 end to end).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    from lvae import _native
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return _native.lib()
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gemm(L, **kw):
+    from lvae._native import GemmDesc
+    d = GemmDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
+    rc = L.lvae_gemm_f32(ctypes.byref(d), _st())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('M,N,K', [(96, 2048, 512), (1000, 512, 2048), (24576, 384, 192), (777, 48, 128), (300, 64, 512),
+                                   (513, 96, 384), (129, 16, 256), (2050, 192, 128), (64, 448, 256), (4096, 256, 8)])
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+def test_gemm_plain(L, M, N, K, epi):
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N * 3 + K + epi)
+    A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    out = torch.full((M, N), float('nan'), device='cuda')
+    _gemm(L, A0=A, lda0=K, K0=K, Wt=Wt, ldw=K, bias=bias, gamma=gamma, res=res, ldres=N, out=out, ldo=N, M=M, N=N, K=K,
+          a_mode=0, epi=epi, store=0)
+    ref = A.double() @ Wt.double().t() + bias.double()
+    if epi == 1:
+        ref = F.gelu(ref)
+    elif epi == 2:
+        ref = res.double() + gamma.double() * ref
+    elif epi == 3:
+        ref = res.double() + ref
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_gemm_asymmetric_identity(L):
+    """A = I with an asymmetric W catches a transposed C-write (cdna guide, 'always A=I-check with asymmetric B')."""
+    K = N = 128
+    A = torch.eye(K, device='cuda')
+    Wt = (torch.arange(N * K, device='cuda', dtype=torch.float32).reshape(N, K) % 251) / 251
+    out = torch.empty(K, N, device='cuda')
+    _gemm(L, A0=A, lda0=K, K0=K, Wt=Wt, ldw=K, bias=torch.zeros(N, device='cuda'), out=out, ldo=N, M=K, N=N, K=K)
+    assert torch.equal(out, Wt.t().contiguous())
+
+
+def test_gemm_concat_inplace_res(L):
+    g = torch.Generator().manual_seed(5)
+    M, K0, K1, N = 700, 256, 384, 256
+    A0, A1 = torch.randn(M, K0, generator=g).cuda(), torch.randn(M, K1, generator=g).cuda()
+    Wt = (torch.randn(N, K0 + K1, generator=g) / 25).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    out = torch.empty(M, N, device='cuda')
+    _gemm(L, A0=A0, lda0=K0, K0=K0, A1=A1, lda1=K1, K1=K1, Wt=Wt, ldw=K0 + K1, bias=bias, out=out, ldo=N, M=M, N=N, K=K0 + K1)
+    ref = torch.cat([A0, A1], 1).double() @ Wt.double().t() + bias.double()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    # in-place residual (fuse_feature_and_z): out aliases res
+    f = torch.randn(M, N, generator=g).cuda()
+    f0 = f.clone()
+    z = torch.randn(M, 8, generator=g).cuda()
+    Wz = torch.randn(N, 8, generator=g).cuda()
+    _gemm(L, A0=z, lda0=8, K0=8, Wt=Wz, ldw=8, bias=bias, res=f, ldres=N, out=f, ldo=N, M=M, N=N, K=8, epi=3)
+    ref = f0.double() + z.double() @ Wz.double().t() + bias.double()
+    assert (f.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('B,Ho,Wo,Cin,Cout', [(2, 6, 10, 192, 384), (1, 3, 5, 512, 512), (3, 1, 1, 384, 512)])
+def test_gemm_patch2(L, B, Ho, Wo, Cin, Cout):
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, Cin, 2 * Ho, 2 * Wo, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 2, 2, generator=g) / (4 * Cin) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = torch.empty(B * Ho * Wo, Cout, device='cuda')
+    _gemm(L, A0=xn, K0=Cin, H=Ho, W=Wo, Wt=wp, ldw=4 * Cin, bias=b, out=out, ldo=Cout, M=B * Ho * Wo, N=Cout, K=4 * Cin, a_mode=1)
+    assert (out.view(B, Ho, Wo, Cout).double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,C,z', [(2, 5, 7, 256, 8), (1, 4, 6, 384, 96), (2, 2, 3, 512, 32), (1, 1, 1, 512, 32)])
+def test_gemm_conv3(L, B, H, W, C, z):
+    g = torch.Generator().manual_seed(C + z)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(z, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    b = torch.randn(z, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = w.permute(0, 2, 3, 1).reshape(z, -1).contiguous()
+    out = torch.empty(B * H * W, z, device='cuda')
+    _gemm(L, A0=xn, K0=C, H=H, W=W, Wt=wp, ldw=9 * C, bias=b, out=out, ldo=z, M=B * H * W, N=z, K=9 * C, a_mode=2)
+    assert (out.view(B, H, W, z).double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,r', [(2, 3, 5, 512, 384, 2), (1, 4, 4, 256, 128, 2)])
+def test_gemm_pixel_shuffle(L, B, H, W, Cin, Cout, r):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout * r * r, Cin, 1, 1, generator=g) / Cin ** 0.5).cuda()
+    b = torch.randn(Cout * r * r, generator=g).cuda()
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double()), r).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = w.reshape(Cout, r * r, Cin).permute(1, 0, 2).reshape(r * r * Cout, Cin).contiguous()
+    bp = b.reshape(Cout, r * r).t().reshape(-1).contiguous()
+    out = torch.full((B, H * r, W * r, Cout), float('nan'), device='cuda')
+    _gemm(L, A0=xn, lda0=Cin, K0=Cin, H=H, W=W, Wt=wp, ldw=Cin, bias=bp, out=out, M=B * H * W, N=Cout * r * r, K=Cin, store=2, r=r)
+    assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemm_final_image(L):
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin = 2, 6, 9, 128
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(48, Cin, 1, 1, generator=g) / 4).cuda()
+    b = torch.randn(48, generator=g).cuda()
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double()), 4).clamp(-1, 1) * 0.5 + 0.5
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.full((B, 3, H * 4, W * 4), float('nan'), device='cuda')
+    _gemm(L, A0=xn, lda0=Cin, K0=Cin, H=H, W=W, Wt=w.reshape(48, Cin).contiguous(), ldw=Cin, bias=b, out=out, M=B * H * W,
+          N=48, K=Cin, store=3, r=4)
+    assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemm_batch_invariance(L):
+    """Rows must be bit-identical whatever M / tile configuration: encoder (batched) and decoder (maybe not) must
+    derive the same priors (SURVEY.md 'hard parts: enc/dec bit-consistency')."""
+    g = torch.Generator().manual_seed(11)
+    K, N = 512, 2048
+    A = torch.randn(8 * 96, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    big = torch.empty(8 * 96, N, device='cuda')
+    _gemm(L, A0=A, lda0=K, K0=K, Wt=Wt, ldw=K, bias=bias, out=big, ldo=N, M=8 * 96, N=N, K=K, epi=1)
+    for i in (0, 5):
+        small = torch.empty(96, N, device='cuda')
+        _gemm(L, A0=A[i * 96:(i + 1) * 96].contiguous(), lda0=K, K0=K, Wt=Wt, ldw=K, bias=bias, out=small, ldo=N, M=96, N=N, K=K, epi=1)
+        assert torch.equal(small, big[i * 96:(i + 1) * 96])
+    A2 = torch.randn(24576, 192, generator=g).cuda()
+    W2 = (torch.randn(384, 192, generator=g) / 14).cuda()
+    b2 = torch.randn(384, generator=g).cuda()
+    o1, o2 = torch.empty(24576, 384, device='cuda'), torch.empty(300, 384, device='cuda')
+    _gemm(L, A0=A2, lda0=192, K0=192, Wt=W2, ldw=192, bias=b2, out=o1, ldo=384, M=24576, N=384, K=192)
+    _gemm(L, A0=A2[5000:5300].contiguous(), lda0=192, K0=192, Wt=W2, ldw=192, bias=b2, out=o2, ldo=384, M=300, N=384, K=192)
+    assert torch.equal(o2, o1[5000:5300])
+
+
+@pytest.mark.parametrize('C,k', [(128, 7), (192, 7), (256, 7), (384, 5), (384, 7), (512, 1), (512, 3), (512, 5), (512, 7)])
+@pytest.mark.parametrize('B,H,W', [(2, 9, 11), (1, 1, 1), (1, 2, 6)])
+def test_dwconv_ln(L, C, k, B, H, W):
+    g = torch.Generator().manual_seed(C * 10 + k + H)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(C, 1, k, k, generator=g) / k).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    shift, scale = torch.randn(C, generator=g).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=(k - 1) // 2, groups=C).permute(0, 2, 3, 1)
+    y = F.layer_norm(y, (C,), eps=1e-6) * (1 + scale.double()) + shift.double()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = w.reshape(C, k * k).t().contiguous()
+    out = torch.full((B, H, W, C), float('nan'), device='cuda')
+    rc = L.lvae_dwconv_ln_f32(xn.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, shift.data_ptr(),
+                              (1 + scale).contiguous().data_ptr(), out.data_ptr(), B, H, W, C, k, _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out.double() - y).abs().max().item() < 3e-5
+    # affine-LN variant (qres34m MyConvNeXtBlock)
+    lw, lb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    y2 = F.conv2d(x.double(), w.double(), b.double(), padding=(k - 1) // 2, groups=C).permute(0, 2, 3, 1)
+    y2 = F.layer_norm(y2, (C,), lw.double(), lb.double(), eps=1e-6)
+    rc = L.lvae_dwconv_ln_f32(xn.data_ptr(), wp.data_ptr(), b.data_ptr(), lw.data_ptr(), lb.data_ptr(), None, None,
+                              out.data_ptr(), B, H, W, C, k, _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out.double() - y2).abs().max().item() < 3e-5
+
+
+def test_stem(L):
+    g = torch.Generator().manual_seed(1)
+    B, H, W, Cout = 2, 24, 40, 192
+    im = torch.rand(B, 3, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 4, 4, generator=g) / 7).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    sh, sc = -0.4546259594901961, 3.67572653978347
+    ref = F.conv2d((im.double() + sh) * sc, w.double(), b.double(), stride=4).permute(0, 2, 3, 1)
+    out = torch.full((B, H // 4, W // 4, Cout), float('nan'), device='cuda')
+    rc = L.lvae_stem_f32(im.data_ptr(), w.reshape(Cout, 48).t().contiguous().data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W,
+                         Cout, sh, sc, _st())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemv(L):
+    g = torch.Generator().manual_seed(2)
+    N, K = 1000, 256
+    Wt, b, x = torch.randn(N, K, generator=g).cuda() / 16, torch.randn(N, generator=g).cuda(), torch.randn(K, generator=g).cuda()
+    y = torch.empty(N, device='cuda')
+    for gi, go in ((0, 0), (1, 0), (0, 1)):
+        assert L.lvae_gemv_f32(Wt.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), N, K, gi, go, _st()) == 0
+        torch.cuda.synchronize()
+        xin = F.gelu(x.double()) if gi else x.double()
+        ref = Wt.double() @ xin + b.double()
+        ref = F.gelu(ref) if go else ref
+        assert (y.double() - ref).abs().max().item() < 1e-5
+
+
+def test_prior_index_quantize_dequantize(L):
+    """Integer outputs must be EXACT against the reference formulation computed by torch on the same device values
+    away from decision boundaries, and against an fp64 evaluation elsewhere."""
+    g = torch.Generator().manual_seed(4)
+    B, HW, z = 3, 35, 32
+    M = B * HW
+    prm = (torch.randn(M, 2 * z, generator=g) * 2).cuda()
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).cuda()
+    pm, idx = torch.empty(M, z, device='cuda'), torch.empty(B, z, HW, dtype=torch.uint8, device='cuda')
+    assert L.lvae_prior_index_f32(prm.data_ptr(), pm.data_ptr(), idx.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pm, prm[:, :z])
+    pv64 = torch.exp(F.softplus(prm[:, z:].double() + 2.3) - 2.3)
+    s64 = torch.clamp(pv64, min=float(table[0]))
+    ref = (table.double()[None, None, :63] < s64[..., None]).sum(-1)            # #{i<63: table[i] < s}
+    ref = ref.view(B, HW, z).permute(0, 2, 1)
+    near = ((s64[..., None] / table.double()[None, None, :] - 1).abs().min(-1)[0] < 1e-5).view(B, HW, z).permute(0, 2, 1)
+    assert torch.equal(idx.long()[~near], ref[~near])
+    # quantize / dequantize
+    qm = (torch.randn(M, z, generator=g) * 6).cuda()
+    sym, zhat = torch.empty(B, z, HW, dtype=torch.int32, device='cuda'), torch.empty(M, z, device='cuda')
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, _st()) == 0
+    torch.cuda.synchronize()
+    r = torch.round(qm - pm)
+    assert torch.equal(sym, r.int().view(B, HW, z).permute(0, 2, 1).contiguous())
+    assert torch.equal(zhat, r + pm)
+    z2 = torch.empty(M, z, device='cuda')
+    assert L.lvae_dequantize_f32(sym.data_ptr(), pm.data_ptr(), z2.data_ptr(), B, HW, z, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z2, zhat)
+    # half-way cases: round-half-to-even
+    qh = torch.tensor([[0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, 4.5]], device='cuda')
+    ph = torch.zeros_like(qh)
+    sh, zh = torch.empty(1, 8, 1, dtype=torch.int32, device='cuda'), torch.empty(1, 8, device='cuda')
+    assert L.lvae_quantize_f32(qh.data_ptr(), ph.data_ptr(), sh.data_ptr(), zh.data_ptr(), 1, 1, 8, _st()) == 0
+    torch.cuda.synchronize()
+    assert sh.flatten().tolist() == [0, 2, 2, 0, -2, -2, 4, 4]
+
+
+def test_sqerr(L):
+    a, b = torch.rand(2, 3 * 70 * 90, device='cuda'), torch.rand(2, 3 * 70 * 90, device='cuda')
+    out = torch.zeros(2, dtype=torch.float64, device='cuda')
+    assert L.lvae_sqerr_sum_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), 2, a.shape[1], _st()) == 0
+    torch.cuda.synchronize()
+    ref = (a.double() - b.double()).square().sum(1)
+    assert torch.allclose(out, ref, rtol=1e-12)
