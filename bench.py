@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: Mpixels/s of encode+decode (qarv_base, batch of 8 synthetic 512x768 images per
+GPU) with the speedtest-lvae.py protocol (/root/reference/scripts/speedtest-lvae.py:13-44): image tensors already
+resident in HBM, `compress` then `decompress`, device sync after each phase, host rANS coding INSIDE the timed region.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one pass of the hot path over one batch: compress_batch(8 images) + decompress_batch(8 strings).
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (fp32-MFMA MLP GEMMs, 87% of the path's FLOPs): algorithmic FLOPs of those
+                  launches / their HIP-event-measured durations over the timed region, against 157.3 TFLOP/s;
+  cpu_baseline -- the CPU oracle (oracle/qarv_oracle.py: the reference's op graph on PyTorch CPU + the plain-C
+                  restatement of CompressAI's coder) timed on this node's host cores on a bounded sample.
+Weights are seeded random-init of the qarv_base architecture (no network for checkpoints); data is synthetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'lossy-vae_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def build_model(device):
+    import lvae
+    import seeded_init
+    m = lvae.get_model('qarv_base')
+    sd = m.state_dict()
+    for k in list(sd.keys()):
+        a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0)
+        if a is not None:
+            sd[k] = torch.from_numpy(a)
+    m.load_state_dict(sd)
+    m = m.to(device)
+    m.eval()
+    m.compress_mode()
+    return m, sd
+
+
+def synth_batch(B, H, W, rank):
+    import seeded_init
+    ims = [seeded_init.synthetic_image_u8(H, W, seed=1000 + rank * 64 + i) for i in range(B)]
+    x = torch.from_numpy(np.stack(ims)).permute(0, 3, 1, 2).float().div(255)
+    return x.contiguous()
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they are launched on (torch's current stream)."""
+    def __init__(self):
+        self.pairs = []
+
+    def wrap(self, plan, pred):
+        """Return a run(lo,hi) replacement for `plan` that brackets ops selected by pred(label) with events."""
+        timer = self
+        ops = plan.ops
+        flops = getattr(plan, 'op_flops', None)
+
+        def run(lo=0, hi=None, stream=None):
+            import ctypes
+            s = torch.cuda.current_stream(plan.device)
+            sp = ctypes.c_void_p(s.cuda_stream)
+            for i, (fn, args, label) in enumerate(ops[lo:hi]):
+                sel = pred(label)
+                if sel:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(s)
+                rc = fn(*args, sp)
+                if rc != 0:
+                    raise RuntimeError(f'{label}: rc={rc}')
+                if sel:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(s)
+                    timer.pairs.append((e0, e1, label))
+        return run
+
+    def summary(self):
+        tot = 0.0
+        for e0, e1, _ in self.pairs:
+            tot += e0.elapsed_time(e1)
+        return tot, len(self.pairs)
+
+
+def cpu_baseline(sd, H, W, n_images=2):
+    """Bounded sample of the same workload on the host: oracle enc+dec of n_images 512x768 images (after 1 warm-up)."""
+    from oracle import qarv_oracle
+    orc = qarv_oracle.QarvOracle({k: v for k, v in sd.items()})
+    orc.compress_mode()
+    cores = torch.get_num_threads()
+    ims = synth_batch(n_images + 1, H, W, rank=99)
+    s = orc.compress(ims[0:1]); orc.decompress(s)          # warm-up
+    t0 = time.time()
+    for i in range(1, n_images + 1):
+        s = orc.compress(ims[i:i + 1])
+        orc.decompress(s)
+    dt = time.time() - t0
+    return {'value': round(n_images * H * W / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{n_images} synthetic {H}x{W} images enc+dec (after 1 warm-up image), oracle/qarv_oracle.py: PyTorch-CPU '
+                      f'fp32 op graph + plain-C CompressAI-style rANS via Python lists, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--height', type=int, default=512)
+    ap.add_argument('--width', type=int, default=768)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    B, H, W = args.batch, args.height, args.width
+    model, sd = build_model(dev)
+    ims = synth_batch(B, H, W, rank).to(dev)
+
+    def step():
+        strings = model.compress_batch(ims)
+        torch.cuda.synchronize(dev)
+        t_mid = time.time()
+        out = model.decompress_batch(strings)
+        torch.cuda.synchronize(dev)
+        return strings, out, t_mid
+
+    for _ in range(args.warmup):
+        strings, out, _ = step()
+
+    timer = KernelTimer()
+    if not args.no_kernel_timing:
+        dominant = lambda label: label.endswith('.fc1') or label.endswith('.fc2')      # noqa: E731
+        for pl in model._plans.values():
+            pl.run = timer.wrap(pl, dominant)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.time()
+    t_enc = 0.0
+    for _ in range(args.steps):
+        ts = time.time()
+        strings, out, t_mid = step()
+        t_enc += t_mid - ts
+    barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([dt, t_enc], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_enc = float(t[0]), float(t[1])
+
+    # rate / distortion stats of this rank's batch, collated over ranks with one all_gather
+    bpp = float(np.mean([len(s) * 8 / (H * W) for s in strings]))
+    mse = float((out - ims).square().mean())
+    stats = torch.tensor([bpp, mse], dtype=torch.float64, device=dev)
+    if dist is not None:
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        stats = torch.stack(gathered).mean(0)
+    bpp, mse = float(stats[0]), float(stats[1])
+
+    roof = None
+    if not args.no_kernel_timing:
+        ms, n_launch = timer.summary()
+        flops = 0
+        for pl in model._plans.values():
+            pass
+        # algorithmic FLOPs of the timed launches: 2*M*N*K per MLP GEMM (bias/GELU/residual epilogues not counted)
+        import ctypes
+        from lvae._native import GemmDesc
+        per_step = 0
+        for pl in model._plans.values():
+            for fn, a, label in pl.ops:
+                if label.endswith('.fc1') or label.endswith('.fc2'):
+                    d = ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
+                    per_step += 2 * d.M * d.N * d.K
+        flops = per_step * args.steps
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<*,PLAIN> (ConvNeXt MLP fc1/fc2, fp32 v_mfma_f32_32x32x2_f32)',
+                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
+                'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3)}
+
+    if rank == 0:
+        px = world * B * H * W * args.steps
+        line = {
+            'metric': 'Mpixels/s enc+dec (qarv_base, 512x768)', 'value': round(px / dt / 1e6, 3), 'unit': 'Mpixels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
+                                   f'fp32 HIP kernels + host rANS, seeded random-init weights', 'global_batch': world * B,
+                       'parallelism': f'dp{world} (images sharded, no data-path collective)',
+                       'lambda': model.default_lmb},
+            'enc_ms_per_step': round(t_enc / args.steps * 1e3, 3),
+            'dec_ms_per_step': round((dt - t_enc) / args.steps * 1e3, 3),
+            'bpp': round(bpp, 4), 'psnr_db': round(-10 * np.log10(mse), 3),
+            'ref_3080ti_mpx_s': 2.47,
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd, H, W)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -55,11 +55,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
         const f32x4 bv = *(const f32x4*)(bias + c);
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[v][t] = bv;
-#pragma unroll
+        // kernel rows are a RUNTIME loop on purpose: fully unrolled, hipcc hoists all (TW+k-1)*k loads of a channel
+        // chunk to the top and spills kilobytes per lane to scratch (measured: 3.7 KB/lane, 16x slower).
+#pragma unroll 1
         for (int i = 0; i < KS; ++i) {
             const int hh = h + i - P;
             const bool rv = (hh >= 0) && (hh < H);
             const float* xrow = x + ((brow + hh) * W) * (long)C + c;
+            const float* wrow = wt + (long)(i * KS) * C + c;
             f32x4 xr[TW + KS - 1];
 #pragma unroll
             for (int q = 0; q < TW + KS - 1; ++q) {
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                const f32x4 wv = *(const f32x4*)(wt + (long)(i * KS + j) * C + c);
+                const f32x4 wv = *(const f32x4*)(wrow + (long)j * C);
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     acc[v][t][0] = fmaf(xr[t + j][0], wv[0], acc[v][t][0]);

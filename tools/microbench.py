@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""GPU micro-benchmarks of the native kernels on the shapes qarv_base uses (B images of 512x768).
+    python tools/microbench.py [gemm|dw|all] [B]
+Prints per-shape time, TFLOP/s (GEMM, algorithmic 2MNK) or GB/s (dwconv+LN, algorithmic read+write of the map)."""
+import ctypes
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'lossy-vae_amd'))
+import torch  # noqa: E402
+from lvae import _native  # noqa: E402
+from lvae._native import GemmDesc  # noqa: E402
+
+L = _native.lib()
+
+
+def st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def bench_gemm(M, N, K, epi):
+    A = torch.randn(M, K, device='cuda')
+    Wt = torch.randn(N, K, device='cuda') / K ** 0.5
+    bias, gamma = torch.randn(N, device='cuda'), torch.rand(N, device='cuda')
+    res = torch.randn(M, N, device='cuda')
+    out = torch.empty(M, N, device='cuda')
+    d = GemmDesc()
+    d.A0, d.lda0, d.K0, d.Wt, d.ldw, d.bias, d.gamma = A.data_ptr(), K, K, Wt.data_ptr(), K, bias.data_ptr(), gamma.data_ptr()
+    d.res, d.ldres, d.out, d.ldo, d.M, d.N, d.K, d.epi = res.data_ptr(), N, out.data_ptr(), N, M, N, K, epi
+    t = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(d), st()))
+    return t
+
+
+def bench_dw(B, H, W, C, k):
+    x = torch.randn(B, H, W, C, device='cuda')
+    w = torch.randn(k * k, C, device='cuda')
+    b, sh, sc = torch.randn(C, device='cuda'), torch.randn(C, device='cuda'), torch.randn(C, device='cuda')
+    y = torch.empty_like(x)
+    t = timeit(lambda: L.lvae_dwconv_ln_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, sh.data_ptr(), sc.data_ptr(),
+                                            y.data_ptr(), B, H, W, C, k, st()))
+    return t
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    px = {4: 24576, 8: 6144, 16: 1536, 32: 384, 64: 96}
+    if what in ('gemm', 'all'):
+        print(f'--- GEMM (fc1: epi=GELU, fc2: epi=gamma+res), B={B}')
+        shapes = [(4, 192, 384), (8, 384, 768), (16, 512, 1024), (32, 512, 1024), (64, 512, 1024), (64, 512, 2048),
+                  (32, 512, 1536), (16, 384, 768), (8, 256, 448), (8, 256, 512), (4, 128, 192)]
+        tot_t = tot_f = 0
+        for s, C, Hd in shapes:
+            M = B * px[s]
+            for (n, k, epi, nm) in ((Hd, C, 1, 'fc1'), (C, Hd, 2, 'fc2')):
+                t = bench_gemm(M, n, k, epi)
+                fl = 2.0 * M * n * k
+                print(f's{s:<2} {nm} M={M:7d} N={n:5d} K={k:5d}  {t * 1e6:9.1f} us  {fl / t / 1e12:7.2f} TF/s')
+                tot_t += t; tot_f += fl
+        print(f'total {tot_t * 1e3:.2f} ms, {tot_f / tot_t / 1e12:.2f} TF/s aggregate')
+    if what in ('dw', 'all'):
+        print(f'--- dwconv+LN+AdaLN, B={B}')
+        for (s, C, k) in [(4, 192, 7), (8, 384, 7), (16, 512, 5), (16, 512, 7), (32, 512, 3), (64, 512, 1), (16, 384, 5),
+                          (8, 256, 7), (4, 128, 7), (8, 384, 7)]:
+            H, W = 512 // s, 768 // s
+            t = bench_dw(B, H, W, C, k)
+            byts = 2.0 * B * H * W * C * 4
+            print(f's{s:<2} C={C:4d} k={k}  {t * 1e6:9.1f} us  {byts / t / 1e9:8.1f} GB/s (algorithmic r+w)')
+
+
+if __name__ == '__main__':
+    main()

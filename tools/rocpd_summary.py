@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Per-kernel summary (calls, total/avg/min/max duration, % of GPU kernel time) from a rocprofv3 rocpd .db
+(`rocprofv3 --kernel-trace --stats`), equivalent to its kernel_stats table.  Usage: rocpd_summary.py x_results.db"""
+import re
+import sqlite3
+import sys
+
+
+def main(path, top=40):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tables = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tables if t.startswith('rocpd_kernel_dispatch')][0]
+    ks = [t for t in tables if t.startswith('rocpd_info_kernel_symbol')][0]
+    cols = [r[1] for r in cur.execute(f'pragma table_info({kd})')]
+    scols = [r[1] for r in cur.execute(f'pragma table_info({ks})')]
+    namecol = 'display_name' if 'display_name' in scols else 'kernel_name'
+    rows = cur.execute(f'select s.{namecol}, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id').fetchall()
+    agg = {}
+    for name, dur in rows:
+        name = re.sub(r'\s+', ' ', name)
+        a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+    tot = sum(a[1] for a in agg.values())
+    print(f'# {path}: {len(rows)} dispatches, total kernel time {tot / 1e6:.3f} ms')
+    print(f'{"calls":>7} {"total_ms":>10} {"avg_us":>10} {"min_us":>9} {"max_us":>9} {"pct":>6}  kernel')
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f'{a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100 * a[1] / tot:6.2f}  {name[:150]}')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
