@@ -82,5 +82,19 @@ def main():
             print(f's{s:<2} C={C:4d} k={k}  {t * 1e6:9.1f} us  {byts / t / 1e9:8.1f} GB/s (algorithmic r+w)')
 
 
+
+
+def gemmx():
+    """Diagnostic sweep: main-loop efficiency vs K, epilogue cost."""
+    for (M, N, K, epi) in [(49152, 768, 384, 0), (49152, 768, 384, 1), (49152, 768, 4096, 0), (49152, 768, 4096, 1),
+                           (8192, 768, 4096, 0), (16384, 4096, 4096, 0), (49152, 384, 768, 0), (49152, 384, 768, 2),
+                           (196608, 384, 192, 0), (196608, 384, 192, 1), (196608, 128, 192, 0), (196608, 128, 2048, 0)]:
+        t = bench_gemm(M, N, K, epi)
+        print(f'M={M:7d} N={N:5d} K={K:5d} epi={epi}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.2f} TF/s')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'gemmx':
+        gemmx()
+    else:
+        main()
