@@ -29,6 +29,14 @@
 
 #include "../../include/lvae_hip.h"
 
+#ifdef LVAE_GEMM_TRACE
+extern "C" __device__ long* lvae_trace_buf;          // [16 k-tiles][8 stamps], filled by one wave of one block
+// stamps go to LDS (beyond the tiles) so that they do not sit on the vmcnt queue the loader waits on; dumped at the end
+#define TRACE_STAMP(slot) do { if (tracing && kt < 16) ((long*)(smem + 2 * (C::BM + C::BN) * LDT))[kt * 8 + (slot)] = clock64(); } while (0)
+#else
+#define TRACE_STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,20 +47,46 @@ constexpr int LDT = BK + 4;   // padded LDS row (floats)
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// 4x4 transpose across the 4 lanes of a quad with DPP quad_perm moves (lane^1: [1,0,3,2] = 0xB1, lane^2: [2,3,0,1] =
+// 0x4E): afterwards lane j holds in (v0..v3) what lanes 0..3 of its quad held in register j.  Used to turn the MFMA
+// accumulator layout (4 consecutive ROWS per lane) into 4 consecutive COLUMNS per lane => 16-B stores / residual loads.
+__device__ __forceinline__ float dpp_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int j) {
+    const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
+    float t;
+    t = dpp_xor1(o1 ? v0 : v1); if (o1) v0 = t; else v1 = t;
+    t = dpp_xor1(o1 ? v2 : v3); if (o1) v2 = t; else v3 = t;
+    t = dpp_xor2(o2 ? v0 : v2); if (o2) v0 = t; else v2 = t;
+    t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
+}
+
 template <int WGM_, int WGN_, int TM_, int TN_>
 struct Cfg {
     static constexpr int WGM = WGM_, WGN = WGN_, TM = TM_, TN = TN_;
+    static constexpr int NT = 64 * WGM * WGN;     // threads per workgroup (4 or 8 wave64)
     static constexpr int BM = WGM * TM * 32;
     static constexpr int BN = WGN * TN * 32;
-    static constexpr int NA = BM * 8 / 256;   // float4 loads per thread per k-tile (A)
-    static constexpr int NB = BN * 8 / 256;   // (W)
+    static constexpr int RP = NT / 8;             // tile rows staged per pass (8 lanes x 16 B = one 128-B row segment)
+    static constexpr int NA = (BM + RP - 1) / RP; // float4 loads per thread per k-tile (A)
+    static constexpr int NB = (BN + RP - 1) / RP; // (W)
+#ifdef LVAE_GEMM_TRACE
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDT * 4 + 1024;
+#else
     static constexpr int LDS_BYTES = 2 * (BM + BN) * LDT * 4;
-    static_assert(WGM * WGN == 4, "4 waves");
-    static_assert(NA >= 1 && NB >= 1, "tile too small");
+#endif
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
+    static_assert(BM % RP == 0, "A tile must be a whole number of staging passes");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-struct RowInfo {      // per staged A row of this thread
-    long off;         // PLAIN: row index m; PATCH2/CONV3: element offset of the row's first tap; -1 = beyond M
+struct RowInfo {      // per staged A row of this thread (rows beyond M are clamped to M-1: loaded, never stored)
+    const float* p0;  // PLAIN: A0 + m*lda0;      PATCH2/CONV3: address of the row's own pixel / first tap
+    const float* p1;  // PLAIN: A1 + m*lda1 - K0  (so that p1 + k is the element for k >= K0)
     int h, w;         // CONV3: pixel coordinates
 };
 
@@ -60,43 +94,51 @@ template <int AMODE>
 __device__ __forceinline__ RowInfo row_info(const lvae_gemm_desc& d, int m) {
     RowInfo ri;
     ri.h = ri.w = 0;
-    if (m >= d.M) { ri.off = -1; return ri; }
+    m = m < d.M ? m : d.M - 1;
+    ri.p1 = nullptr;
     if (AMODE == LVAE_A_PLAIN) {
-        ri.off = m;
+        ri.p0 = d.A0 + (long)m * d.lda0;
+        ri.p1 = d.A1 ? d.A1 + (long)m * d.lda1 - d.K0 : ri.p0;
     } else if (AMODE == LVAE_A_PATCH2) {
         const int w = m % d.W, bh = m / d.W;          // bh = b*H + h on the OUTPUT grid; input rows 2*bh, 2*bh+1
-        ri.off = ((long)bh * 2 * (2L * d.W) + 2L * w) * d.K0;
+        ri.p0 = d.A0 + ((long)bh * 2 * (2L * d.W) + 2L * w) * d.K0;
     } else {
         const int w = m % d.W, bh = m / d.W;
         ri.w = w;
         ri.h = bh % d.H;
-        ri.off = (long)m * d.K0;
+        ri.p0 = d.A0 + (long)m * d.K0;
     }
     return ri;
 }
 
+// Branch-free operand fetch: ONE unconditional 16-B load per staged element from an always-valid address; elements
+// that must read as zero (k beyond K, 3x3 taps outside the image) are flagged in `ok` and zeroed when the registers
+// are written to LDS.  (Divergent "if (valid) load" forms make hipcc guard every load with s_waitcnt vmcnt(0) --
+// WAW on the destination registers -- which serialises the 8 loads of a k-tile: measured 1200-3000 cycles per tile.)
 template <int AMODE>
-__device__ __forceinline__ f32x4 load_a(const lvae_gemm_desc& d, const RowInfo& ri, int k) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (ri.off < 0 || k >= d.K) return z;
+__device__ __forceinline__ f32x4 load_a(const lvae_gemm_desc& d, const RowInfo& ri, int k, bool& ok) {
+    ok = k < d.K;
+    const int kc = ok ? k : d.K - 4;
     if (AMODE == LVAE_A_PLAIN) {
-        if (k < d.K0) return *(const f32x4*)(d.A0 + ri.off * d.lda0 + k);
-        return *(const f32x4*)(d.A1 + ri.off * d.lda1 + (k - d.K0));
+        const float* p = (kc < d.K0) ? ri.p0 : ri.p1;
+        return *(const f32x4*)(p + kc);
     } else if (AMODE == LVAE_A_PATCH2) {
         const int seg = 2 * d.K0;                 // one input row of the 2x2 patch: 2 pixels x Cin
-        const int s = k / seg, kk = k - s * seg;
-        return *(const f32x4*)(d.A0 + ri.off + (long)s * (2L * d.W) * d.K0 + kk);
+        const int s = kc / seg, kk = kc - s * seg;
+        return *(const f32x4*)(ri.p0 + (long)s * (2L * d.W) * d.K0 + kk);
     } else {
-        const int s = k / d.K0, kk = k - s * d.K0;
+        const int s = kc / d.K0, kk = kc - s * d.K0;
         const int di = s / 3 - 1, dj = s - (s / 3) * 3 - 1;
         const int hh = ri.h + di, ww = ri.w + dj;
-        if (hh < 0 || hh >= d.H || ww < 0 || ww >= d.W) return z;
-        return *(const f32x4*)(d.A0 + ri.off + ((long)di * d.W + dj) * d.K0 + kk);
+        const bool in = (hh >= 0) && (hh < d.H) && (ww >= 0) && (ww < d.W);
+        ok = ok && in;
+        const long tap = in ? ((long)di * d.W + dj) * d.K0 : 0;
+        return *(const f32x4*)(ri.p0 + tap + kk);
     }
 }
 
 template <class C, int AMODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
+__global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDT]
     float* Ws = smem + 2 * C::BM * LDT;        // [2][BN][LDT]
@@ -119,12 +161,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvae_gemm_desc d, in
     const int srow = tid >> 3, sk4 = tid & 7;
     RowInfo ri[C::NA];
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i) ri[i] = row_info<AMODE>(d, m0 + srow + 32 * i);
-    long woff[C::NB];
+    for (int i = 0; i < C::NA; ++i) ri[i] = row_info<AMODE>(d, m0 + srow + C::RP * i);
+    const float* wrow[C::NB];
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) {
-        const int n = n0 + srow + 32 * i;
-        woff[i] = n < d.N ? (long)n * d.ldw : -1;
+        const int n = n0 + srow + C::RP * i;
+        wrow[i] = d.Wt + (long)(n < d.N ? n : d.N - 1) * d.ldw;     // columns beyond N: loaded, never stored
     }
 
     f32x16 acc[C::TM][C::TN];
@@ -139,29 +181,49 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvae_gemm_desc d, in
     const int nk = (d.K + BK - 1) / BK;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    unsigned okmask = 0;      // bit i: ra[i] is real data; bit 16: the W chunk is real data (k < K)
     auto gload = [&](int kt) {
         const int k = kt * BK + sk4 * 4;
+        okmask = 0;
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) ra[i] = load_a<AMODE>(d, ri[i], k);
+        for (int i = 0; i < C::NA; ++i) {
+            bool ok;
+            ra[i] = load_a<AMODE>(d, ri[i], k, ok);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+        const bool wok = k < d.K;
+        const int kc = wok ? k : d.K - 4;
+        okmask |= (wok ? 1u : 0u) << 16;
 #pragma unroll
-        for (int i = 0; i < C::NB; ++i) rb[i] = (woff[i] >= 0 && k < d.K) ? *(const f32x4*)(d.Wt + woff[i] + k) : zero4;
+        for (int i = 0; i < C::NB; ++i) rb[i] = *(const f32x4*)(wrow[i] + kc);
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * C::BM * LDT + srow * LDT + sk4 * 4;
         float* w = Ws + buf * C::BN * LDT + srow * LDT + sk4 * 4;
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) *(f32x4*)(a + 32 * i * LDT) = ra[i];
+        for (int i = 0; i < C::NA; ++i) *(f32x4*)(a + C::RP * i * LDT) = ((okmask >> i) & 1u) ? ra[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < C::NB; ++i) *(f32x4*)(w + 32 * i * LDT) = rb[i];
+        for (int i = 0; i < C::NB; ++i)
+            if (C::BN % C::RP == 0 || srow + C::RP * i < C::BN)
+                *(f32x4*)(w + C::RP * i * LDT) = ((okmask >> 16) & 1u) ? rb[i] : zero4;
     };
 
     gload(0);
     lstore(0);
     __syncthreads();
 
+#ifdef LVAE_GEMM_TRACE
+    const bool tracing = (blockIdx.x == gridDim.x / 2 + 3) && tid == 0;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+        TRACE_STAMP(0);
+#if defined(LVAE_GEMM_LOADSAME)
+        if (kt + 1 < nk) gload(kt & 1);
+#elif !defined(LVAE_GEMM_NOLOAD)
         if (kt + 1 < nk) gload(kt + 1);
+#endif
+        TRACE_STAMP(1);
         const float* a_base = As + cur * C::BM * LDT + (wave_m * C::TM * 32 + li) * LDT + 4 * lh;
         const float* b_base = Ws + cur * C::BN * LDT + (wave_n * C::TN * 32 + li) * LDT + 4 * lh;
 #pragma unroll
@@ -179,46 +241,128 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvae_gemm_desc d, in
                     for (int b = 0; b < C::TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
         }
+        TRACE_STAMP(2);
         if (kt + 1 < nk) lstore(cur ^ 1);
+        TRACE_STAMP(3);
         __syncthreads();
+        TRACE_STAMP(4);
     }
 
+#ifdef LVAE_GEMM_TRACE
+    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + 2 * (C::BM + C::BN) * LDT))[i];
+#endif
     // ---------------------------------------------------------------- epilogue
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // acc[][] is only ever indexed statically (a runtime index sends the whole accumulator tile to scratch).
     const int rr = d.r, r2 = rr * rr;
+    const int epi = d.epi, store = d.store;
+    const int cp = (store == LVAE_ST_ROWMAJOR) ? 1 : d.N / r2;
+    const bool vec = (store == LVAE_ST_ROWMAJOR && !(d.N & 3) && !(d.ldo & 3) && !(d.ldres & 3)) ||
+                     (store == LVAE_ST_SHUFFLE && !(cp & 3));
+    if (vec) {
+        // vector path: per-column ops on the lane's own column, quad transpose, then one 16-B access per 4 outputs
+        const int lj = li & 3;
+        float cbias[C::TN], cgam[C::TN];
+        long ccol4[C::TN];
+        bool cok4[C::TN];
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b) {
+            const int colb = n0 + (wave_n * C::TN + b) * 32;
+            const int col = colb + li;
+            const int cc = col < d.N ? col : 0;
+            cbias[b] = d.bias ? d.bias[cc] : 0.f;
+            cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
+            const int c4 = colb + (li & ~3);                 // first of the 4 columns this lane stores
+            cok4[b] = c4 < d.N;
+            const int c4c = cok4[b] ? c4 : 0;
+            if (store == LVAE_ST_ROWMAJOR) {
+                ccol4[b] = c4c;
+            } else {
+                const int q = c4c / cp, sc = c4c - q * cp, si = q / rr, sj = q - si * rr;
+                ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < C::TM; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;     // row this lane stores
+                const bool rok = row < d.M;
+                const int rowc = rok ? row : 0;
+                long obase;
+                if (store == LVAE_ST_ROWMAJOR) {
+                    obase = (long)rowc * d.ldo;
+                } else {
+                    const int w = rowc % d.W, bh = rowc / d.W, h = bh % d.H, bb = bh / d.H;
+                    obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
+                }
+                const float* resrow = d.res + (long)rowc * d.ldres;
+#pragma unroll
+                for (int b = 0; b < C::TN; ++b) {
+                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
+                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
+                    if (epi == LVAE_EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                    else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    if (rok && cok4[b]) {
+                        f32x4 o = {v0, v1, v2, v3};
+                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
+                            const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
+                            o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
+                        }
+                        *(f32x4*)(d.out + obase + ccol4[b]) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // scalar path (final image layer, odd leading dimensions): rows-outer / columns-inner, 4-B accesses
+    float cbias[C::TN], cgam[C::TN];
+    long ccol[C::TN];                 // ROWMAJOR: col; SHUFFLE/IMAGE: column part of the output offset
+    bool cok[C::TN];
 #pragma unroll
     for (int b = 0; b < C::TN; ++b) {
         const int col = n0 + (wave_n * C::TN + b) * 32 + li;
-        if (col >= d.N) continue;
-        const float bias = d.bias ? d.bias[col] : 0.f;
-        const float gam = (d.epi == LVAE_EPI_GAMMA_RES) ? d.gamma[col] : 1.f;
-        int sc = 0, si = 0, sj = 0, cp = 1;          // shuffle decomposition of the column
-        if (d.store == LVAE_ST_SHUFFLE) { cp = d.N / r2; const int q = col / cp; sc = col - q * cp; si = q / rr; sj = q - si * rr; }
-        if (d.store == LVAE_ST_IMAGE)   { cp = d.N / r2; sc = col / r2; const int q = col - sc * r2; si = q / rr; sj = q - si * rr; }
+        cok[b] = col < d.N;
+        const int cc = cok[b] ? col : 0;
+        cbias[b] = d.bias ? d.bias[cc] : 0.f;
+        cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
+        if (store == LVAE_ST_ROWMAJOR) {
+            ccol[b] = cc;
+        } else if (store == LVAE_ST_SHUFFLE) {        // column n' = (i*r+j)*cp + c
+            const int q = cc / cp, sc = cc - q * cp, si = q / rr, sj = q - si * rr;
+            ccol[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
+        } else {                                      // IMAGE: column n = c*r^2 + i*r + j -> NCHW
+            const int sc = cc / r2, q = cc - sc * r2, si = q / rr, sj = q - si * rr;
+            ccol[b] = ((long)sc * (d.H * rr) + si) * (d.W * rr) + sj;
+        }
+    }
 #pragma unroll
-        for (int a = 0; a < C::TM; ++a) {
-            const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
+    for (int a = 0; a < C::TM; ++a) {
+        const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row >= d.M) continue;
-                float v = acc[a][b][r] + bias;
-                if (d.epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
-                else if (d.epi == LVAE_EPI_GAMMA_RES) v = d.res[(long)row * d.ldres + col] + gam * v;
-                else if (d.epi == LVAE_EPI_RES) v = d.res[(long)row * d.ldres + col] + v;
-                if (d.store == LVAE_ST_ROWMAJOR) {
-                    d.out[(long)row * d.ldo + col] = v;
-                } else {
-                    const int w = row % d.W, bh = row / d.W, h = bh % d.H, bb = bh / d.H;
-                    if (d.store == LVAE_ST_SHUFFLE) {
-                        const long pix = ((long)(bb * d.H + h) * rr + si) * (d.W * rr) + (long)w * rr + sj;
-                        d.out[pix * cp + sc] = v;
-                    } else {
-                        v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
-                        const long o = (((long)bb * cp + sc) * (d.H * rr) + (long)h * rr + si) * (d.W * rr) + (long)w * rr + sj;
-                        d.out[o] = v;
-                    }
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row >= d.M) continue;
+            long obase;
+            if (store == LVAE_ST_ROWMAJOR) {
+                obase = (long)row * d.ldo;
+            } else {
+                const int w = row % d.W, bh = row / d.W, h = bh % d.H, bb = bh / d.H;
+                if (store == LVAE_ST_SHUFFLE) obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
+                else obase = ((long)bb * cp * (d.H * rr) + (long)h * rr) * (d.W * rr) + (long)w * rr;
+            }
+            const float* resrow = d.res + (long)row * d.ldres;
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) {
+                if (!cok[b]) continue;
+                float v = acc[a][b][r] + cbias[b];
+                if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
+                else if (epi == LVAE_EPI_GAMMA_RES) v = resrow[ccol[b]] + cgam[b] * v;
+                else if (epi == LVAE_EPI_RES) v = resrow[ccol[b]] + v;
+                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                d.out[obase + ccol[b]] = v;
             }
         }
     }
@@ -235,27 +379,64 @@ int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<C, AMODE>), dim3(n_tiles), dim3(256), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
+    hipLaunchKernelGGL((gemm_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();
 }
 
+// 4-wave configs (2 workgroups per CU): small / narrow problems
 typedef Cfg<2, 2, 2, 2> CfgA;   // 128 x 128, wave 64x64
 typedef Cfg<2, 2, 2, 1> CfgB;   // 128 x 64,  wave 64x32
 typedef Cfg<4, 1, 1, 1> CfgC;   // 128 x 32,  wave 32x32
 typedef Cfg<2, 2, 1, 1> CfgS;   //  64 x 64,  wave 32x32
+// 8-wave configs (1 workgroup per CU, 2 waves per SIMD): the large layers.  A CU ingests only ~10 B/clk from L2/HBM
+// (MI355X_MICROARCH.md: global_load_dwordx4 ~10 B/cyc/CU) while the fp32 MFMA pipes of one CU retire a 32-deep k-step
+// of a BMxBN tile in BM*BN/4 clk, i.e. the operand stream needs 512*(BM+BN)/(BM*BN) B/clk: 8.0 for 128x128 (load-bound,
+// measured 72% MFMA-busy), 5.3 for 256x192, 4.0 for 256x256.
+typedef Cfg<4, 2, 2, 4> CfgL256;   // 256 x 256, wave 64x128
+typedef Cfg<4, 2, 2, 3> CfgL192;   // 256 x 192, wave 64x96
+typedef Cfg<8, 1, 1, 7> CfgL224;   // 256 x 224, wave 32x224  (N = 448 = 1.75 x 256)
+typedef Cfg<4, 2, 2, 2> CfgL128;   // 256 x 128, wave 64x64
+
+constexpr int kCUs = 256;
+
+// Estimated cost (arbitrary units ~ MFMA cycles on the critical CU) of running the problem with a BMxBN tile:
+// rounds of tiles over the CUs (workgroup slots) x per-tile work, plus a per-tile fixed cost (prologue + epilogue).
+inline double tile_cost(int M, int N, int K, int BM, int BN, int wg_per_cu, double eff) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long slots = (long)kCUs * wg_per_cu;
+    const long rounds = (tiles + slots - 1) / slots;
+    const double per_tile = (double)BM * BN * (K + 96.0) * wg_per_cu;   // co-resident workgroups share the MFMA pipes
+    return rounds * per_tile / eff;
+}
 
 template <int AMODE>
 int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
-    const int N = d->N, M = d->M;
+    const int N = d->N, M = d->M, K = d->K;
     if (N <= 32 || N == 96) return launch_cfg<CfgC, AMODE>(d, st);
-    if (N % 128 == 0) {
-        const long tilesA = (long)((M + 127) / 128) * (N / 128);
-        if (tilesA >= 192) return launch_cfg<CfgA, AMODE>(d, st);
-        return launch_cfg<CfgS, AMODE>(d, st);
+    if (N <= 64) return launch_cfg<CfgB, AMODE>(d, st);
+    // candidates: {cost, id}; eff = measured relative MFMA efficiency of the structure
+    double best = 1e300;
+    int id = 0;
+    auto consider = [&](int cid, int BM, int BN, int wg, double eff) {
+        const double c = tile_cost(M, N, K, BM, BN, wg, eff);
+        if (c < best) { best = c; id = cid; }
+    };
+    consider(0, 128, 128, 2, 0.72);
+    consider(1, 128, 64, 2, 0.60);
+    consider(2, 64, 64, 2, 0.50);
+    consider(3, 256, 256, 1, 0.90);
+    consider(4, 256, 192, 1, 0.88);
+    consider(5, 256, 224, 1, 0.85);
+    consider(6, 256, 128, 1, 0.85);
+    switch (id) {
+        case 0: return launch_cfg<CfgA, AMODE>(d, st);
+        case 1: return launch_cfg<CfgB, AMODE>(d, st);
+        case 2: return launch_cfg<CfgS, AMODE>(d, st);
+        case 3: return launch_cfg<CfgL256, AMODE>(d, st);
+        case 4: return launch_cfg<CfgL192, AMODE>(d, st);
+        case 5: return launch_cfg<CfgL224, AMODE>(d, st);
+        default: return launch_cfg<CfgL128, AMODE>(d, st);
     }
-    const long tilesB = (long)((M + 127) / 128) * ((N + 63) / 64);
-    if (tilesB >= 192 || N < 64) return launch_cfg<CfgB, AMODE>(d, st);
-    return launch_cfg<CfgS, AMODE>(d, st);
 }
 
 }  // namespace

@@ -96,5 +96,9 @@ def gemmx():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gemmx':
         gemmx()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gemm1':
+        M, N, K, epi = [int(v) for v in sys.argv[2:6]]
+        t = bench_gemm(M, N, K, epi)
+        print(f'M={M} N={N} K={K} epi={epi} {t * 1e6:.1f} us {2.0 * M * N * K / t / 1e12:.2f} TF/s')
     else:
         main()
