@@ -4,7 +4,7 @@
 // lvae/models/qarv/model.py:107 (encode_with_indexes), :113 (decode_with_indexes), :124 (pmf_to_quantized_cdf)
 // and lvae/models/qresvae/model.py:325,339,356.  The range coder stays on the host (serial by nature) but is
 // fed directly by GPU-produced uint8 scale indexes / int32 symbols in pinned buffers: no Python lists, symbols
-// walked back-to-front in place (no intermediate symbol vector), binary-search decode, and N independent streams
+// walked back-to-front in place (no intermediate symbol vector), bucket-LUT decode, and N independent streams
 // (images x latent blocks) coded on N host threads.
 //
 // Bit-compatible with oracle/rans_oracle.c (the plain restatement of CompressAI's coder); checked in
@@ -178,18 +178,29 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
     uint64_t x = (uint64_t)ptr[0] | ((uint64_t)ptr[1] << 32);
     ptr += 2;
     bool overrun = false;
+    // Per-row 256-bucket start table, built lazily for the rows this stream touches: lut[row][cf >> 8] = largest s
+    // with cdf[s] <= (bucket << 8).  The symbol is then found by a short forward scan (replaces upstream's linear
+    // find_if over up to 249 entries and a branchy binary search; 16 KB, L1-resident).
+    uint8_t lut[256][256];
+    bool have[256] = {false};
     for (size_t i = 0; i < n; ++i) {
         const int32_t row_i = idx[i];
         const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
         const int32_t size = cdf_len[row_i];
         const int32_t max_value = size - 2;
-        const uint32_t cf = (uint32_t)(x & 0xFFFF);
-        // largest s with cdf[s] <= cf  (cdf[0]=0, cdf[size-1]=65536 > cf)
-        int32_t lo = 0, hi = size - 1;
-        while (hi - lo > 1) {
-            const int32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)cdf[mid] <= cf) lo = mid; else hi = mid;
+        if (!have[row_i]) {
+            if (size < 2 || size > 257) return -4;
+            int32_t sidx = 0;
+            for (int b = 0; b < 256; ++b) {
+                const uint32_t v = (uint32_t)b << 8;
+                while (sidx + 1 < size - 1 && (uint32_t)cdf[sidx + 1] <= v) ++sidx;
+                lut[row_i][b] = (uint8_t)sidx;
+            }
+            have[row_i] = true;
         }
+        const uint32_t cf = (uint32_t)(x & 0xFFFF);
+        int32_t lo = lut[row_i][cf >> 8];
+        while ((uint32_t)cdf[lo + 1] <= cf) ++lo;       // cdf[size-1] = 65536 > cf terminates the scan
         const int32_t s = lo;
         const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
         x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFF) - start;

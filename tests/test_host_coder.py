@@ -1,0 +1,157 @@
+"""not-gpu: the product's C++ host coder (liblvae_hip.so, C ABI) against the oracle restatement, bit for bit."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import compressai_semantics as cs
+from oracle.qarv_oracle import DiscretizedGaussianOracle
+
+
+@pytest.fixture(scope='module')
+def L():
+    from lvae import _native
+    return _native.lib()
+
+
+@pytest.fixture(scope='module')
+def tabs():
+    d = DiscretizedGaussianOracle()
+    d.update()
+    return (np.ascontiguousarray(d._quantized_cdf.numpy().astype(np.int32)),
+            np.ascontiguousarray(d._cdf_length.numpy().astype(np.int32)),
+            np.ascontiguousarray(d._offset.numpy().astype(np.int32)), d)
+
+
+def _enc(L, sym, idx, tabs):
+    cdf, ln, off, _ = tabs
+    out = np.empty(8 * sym.size + 64, dtype=np.uint8)
+    n = L.lvae_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, sym.size, cdf.ctypes.data, cdf.shape[1],
+                                        ln.ctypes.data, off.ctypes.data, out.ctypes.data, out.size)
+    assert n >= 8
+    return out[:n].tobytes()
+
+
+def _dec(L, s, idx, tabs):
+    cdf, ln, off, _ = tabs
+    buf = np.frombuffer(s, dtype=np.uint8)
+    out = np.empty(idx.size, dtype=np.int32)
+    rc = L.lvae_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, idx.size, cdf.ctypes.data, cdf.shape[1],
+                                         ln.ctypes.data, off.ctypes.data, out.ctypes.data)
+    return rc, out
+
+
+@pytest.mark.parametrize('n,spread', [(0, 1.0), (1, 1.0), (7, 1.0), (4097, 0.3), (100000, 1.5), (30000, 40.0)])
+def test_streams_match_oracle(L, tabs, n, spread):
+    cdf, ln, off, dg = tabs
+    g = np.random.default_rng(n + 1)
+    idx = g.integers(0, 64, size=n).astype(np.uint8)
+    sym = np.rint(g.normal(0, 1, size=n) * dg.scale_table.numpy()[idx] * spread).astype(np.int32)   # spread 40 => many escapes
+    s = _enc(L, sym, idx, tabs)
+    ref = cs.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist())
+    assert s == ref
+    rc, out = _dec(L, s, idx, tabs)
+    assert rc == 0 and np.array_equal(out, sym)
+    assert cs.RansDecoder().decode_with_indexes(s, idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist()) == sym.tolist()
+
+
+def test_escape_extremes(L, tabs):
+    sym = np.array([0, 2 ** 27 - 300, -(2 ** 27 - 300), 70000, -70000, 3, -3, 5000, -5000], dtype=np.int32)
+    idx = np.array([0, 63, 63, 0, 0, 31, 31, 7, 7], dtype=np.uint8)
+    cdf, ln, off, _ = tabs
+    s = _enc(L, sym, idx, tabs)
+    assert s == cs.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist())
+    rc, out = _dec(L, s, idx, tabs)
+    assert rc == 0 and np.array_equal(out, sym)
+
+
+def test_decode_rejects_garbage(L, tabs):
+    idx = np.zeros(1000, dtype=np.uint8)
+    rc, _ = _dec(L, b'\x00' * 6, idx, tabs)            # too short / not a multiple of 4
+    assert rc < 0
+    rc, _ = _dec(L, b'\xff' * 8, idx, tabs)            # truncated: runs off the stream
+    assert rc < 0
+
+
+def test_small_output_buffer(L, tabs):
+    cdf, ln, off, _ = tabs
+    sym, idx = np.zeros(10000, dtype=np.int32), np.full(10000, 63, dtype=np.uint8)
+    out = np.empty(16, dtype=np.uint8)
+    n = L.lvae_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, sym.size, cdf.ctypes.data, cdf.shape[1],
+                                        ln.ctypes.data, off.ctypes.data, out.ctypes.data, out.size)
+    assert n == -2
+
+
+def test_batch_api_equals_single(L, tabs):
+    from lvae.models.entropy_coding import rans_decode_streams, rans_encode_streams
+    cdf, ln, off, dg = tabs
+    g = np.random.default_rng(9)
+    syms, idxs = [], []
+    for n in (3072, 12288, 0, 147456, 49152, 5):
+        idx = g.integers(0, 64, size=n).astype(np.uint8)
+        syms.append(np.rint(g.normal(0, 1, size=n) * dg.scale_table.numpy()[idx]).astype(np.int32)); idxs.append(idx)
+    for nt in (1, 3, 0):
+        strings = rans_encode_streams((cdf, ln, off), syms, idxs, nt)
+        assert strings == [_enc(L, s, i, tabs) for s, i in zip(syms, idxs)]
+        outs = [np.empty(s.size, dtype=np.int32) for s in syms]
+        rans_decode_streams((cdf, ln, off), strings, idxs, outs, nt)
+        assert all(np.array_equal(a, b) for a, b in zip(outs, syms))
+    with pytest.raises(ValueError):
+        rans_decode_streams((cdf, ln, off), [b'\xff' * 8], [np.zeros(100, np.uint8)], [np.empty(100, np.int32)], 1)
+
+
+def test_pmf_to_quantized_cdf_matches_oracle(L):
+    g = np.random.default_rng(1)
+    for n in (2, 5, 64, 248):
+        for _ in range(25):
+            p = (g.random(n) ** 6).astype(np.float32)
+            p /= p.sum()
+            out = np.zeros(n + 1, dtype=np.uint32)
+            assert L.lvae_pmf_to_quantized_cdf(p.ctypes.data, n, 16, out.ctypes.data) == 0
+            assert out.tolist() == cs.pmf_to_quantized_cdf(p.tolist(), 16)
+    bad = np.array([0.5, -0.1], dtype=np.float32)
+    out = np.zeros(3, dtype=np.uint32)
+    assert L.lvae_pmf_to_quantized_cdf(bad.ctypes.data, 2, 16, out.ctypes.data) == -1
+    z = np.zeros(4, dtype=np.float32)
+    out = np.zeros(5, dtype=np.uint32)
+    assert L.lvae_pmf_to_quantized_cdf(z.ctypes.data, 4, 16, out.ctypes.data) == -2
+
+
+def test_product_update_matches_reference_tables(golden_dir):
+    """lvae.models.entropy_coding.DiscretizedGaussian.update() (torch pmf + native quantiser) == the tables the
+    REFERENCE's DiscretizedGaussian produced (tests/golden/discretized_gaussian_tables.npz), bit for bit."""
+    from lvae.models.entropy_coding import DiscretizedGaussian
+    g = np.load(os.path.join(golden_dir, 'discretized_gaussian_tables.npz'))
+    dg = DiscretizedGaussian(cdf_form='erf')
+    dg.update()
+    assert np.array_equal(dg.scale_table.numpy(), g['scale_table'])
+    assert np.array_equal(dg._quantized_cdf.numpy(), g['quantized_cdf'])
+    assert np.array_equal(dg._cdf_length.numpy(), g['cdf_length'])
+    assert np.array_equal(dg._offset.numpy(), g['offset'])
+    q, l, o = dg.host_tables()
+    assert q.dtype == np.int32 and q.flags['C_CONTIGUOUS'] and q.shape == (64, 249)
+
+
+@pytest.mark.parametrize('form', [0, 1])
+def test_native_table_builder_invariants(L, form):
+    """lvae_build_gaussian_tables (pure C, libm erff/erfcf): same lengths/offsets as the torch-built tables, valid CDF
+    rows, and entries within +-2 counts of them (libm vs torch erf differ by an ulp in places; see include/lvae_hip.h)."""
+    import scipy.stats
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).numpy().astype(np.float32)
+    q = np.zeros((64, 256), dtype=np.int32); ln = np.zeros(64, dtype=np.int32); off = np.zeros(64, dtype=np.int32)
+    mx = L.lvae_build_gaussian_tables(table.ctypes.data, 64, float(-scipy.stats.norm.ppf(0.5e-9)), form, q.ctypes.data, 256,
+                                      ln.ctypes.data, off.ctypes.data)
+    assert mx == 249
+    ref = DiscretizedGaussianOracle() if form == 0 else cs.GaussianConditional(None)
+    if form == 1:
+        ref.update_scale_table(torch.from_numpy(table))
+    else:
+        ref.update()
+    assert np.array_equal(ln, ref._cdf_length.numpy()) and np.array_equal(off, ref._offset.numpy())
+    rq = ref._quantized_cdf.numpy()
+    assert np.abs(q[:, :249] - rq).max() <= 2
+    for i in range(64):
+        row = q[i, :ln[i]]
+        assert row[0] == 0 and row[-1] == 65536 and np.all(np.diff(row) >= 1)

@@ -1,0 +1,100 @@
+"""not-gpu: host-side logic of the drop-in package: registry, state-dict compatibility, containers, padding."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import lvae
+from lvae.utils import coding
+from oracle import qarv_oracle
+
+
+def test_registry_contract():
+    assert 'qarv_base' in lvae.models.registry._all_models
+    with pytest.raises(KeyError):
+        lvae.get_model('no_such_model')
+    assert lvae.get_model is lvae.models.registry.get_model
+
+
+@pytest.fixture(scope='module')
+def model():
+    return lvae.get_model('qarv_base', lmb_range=(16, 2048))
+
+
+def test_state_dict_keys_and_shapes_match_reference_inventory(model):
+    """952 entries (907 parameters + 45 entropy-model buffers), 93.433 M parameters, reference key names."""
+    sd = model.state_dict()
+    assert len(sd) == 952
+    want = dict(qarv_oracle.qarv_param_shapes(qarv_oracle.qarv_base_arch()))
+    have = {k: tuple(v.shape) for k, v in model.named_parameters()}
+    assert have == want
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 93433400
+    bufs = [k for k in sd if k not in have]
+    assert len(bufs) == 45 and all('.discrete_gaussian.' in k for k in bufs)
+    assert {k.rsplit('.discrete_gaussian.', 1)[1] for k in bufs} == {
+        '_offset', '_quantized_cdf', '_cdf_length', 'likelihood_lower_bound.bound', 'lower_bound_scale.bound'}
+
+
+def test_attributes_used_by_the_harness_scripts(model):
+    assert model.max_stride == 64 and model.lmb_range == (16.0, 2048.0) and model.default_lmb == 2048.0
+    assert model.num_latents == 9 and hasattr(model, 'compress_file') and hasattr(model, 'decompress_file')
+    model.default_lmb = 100.0          # eval-var-rate.py:41-42 sets it as a plain attribute
+    assert model.default_lmb == 100.0
+    model.default_lmb = 2048.0
+    assert next(model.parameters()).device.type == 'cpu'
+
+
+def test_compress_mode_before_to_device_builds_tables(model):
+    model.compress_mode()              # eval-fix-rate.py:30 calls it before .to(device)
+    for b in model.dec_blocks:
+        if getattr(b, 'is_latent_block', False):
+            assert tuple(b.discrete_gaussian._quantized_cdf.shape) == (64, 249)
+    sd = model.state_dict()
+    m2 = lvae.get_model('qarv_base')
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict(sd)         # like the reference: empty buffers vs built tables is a size mismatch
+    m2.compress_mode()
+    m2.load_state_dict(sd)
+
+
+def test_cpu_is_refused_loudly(model):
+    model.compress_mode()
+    with pytest.raises(RuntimeError, match='GPU'):
+        model.compress(torch.rand(1, 3, 64, 64))
+
+
+def test_pack_unpack_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pack_byte_strings.npz'))
+    for i in range(3):
+        joined, parts, o = g[f'case{i}.joined'].tobytes(), [], 0
+        for n in g[f'case{i}.lengths'].tolist():
+            parts.append(joined[o:o + n]); o += n
+        packed = coding.pack_byte_strings(parts)
+        assert packed == g[f'case{i}.packed'].tobytes()
+        assert coding.unpack_byte_string(packed) == parts
+    with pytest.raises(AssertionError):
+        coding.unpack_byte_string(coding.pack_byte_strings([b'abc', b'de'])[:-1])
+    assert coding.unpack_byte_string(coding.pack_byte_strings([])) == []
+
+
+def test_pad_divisible_by_and_to_tensor():
+    from PIL import Image
+    a = (np.arange(70 * 100 * 3) % 251).astype(np.uint8).reshape(70, 100, 3)
+    p = coding.pad_divisible_by(Image.fromarray(a), 64)
+    assert (p.height, p.width) == (128, 128)
+    pa = np.asarray(p)
+    assert np.array_equal(pa[:70, :100], a) and np.array_equal(pa[100, :100], a[69]) and np.array_equal(pa[:70, 120], a[:, 99])
+    assert np.array_equal(pa, qarv_oracle.pad_divisible_by_u8(a, 64))
+    same = coding.pad_divisible_by(Image.fromarray(a[:64, :64]), 64)
+    assert (same.height, same.width) == (64, 64)
+    t = coding.pil_to_tensor01(Image.fromarray(a))
+    assert t.shape == (3, 70, 100) and t.dtype == torch.float32 and float(t.max()) <= 1.0
+    assert torch.equal(t, torch.from_numpy(a).permute(2, 0, 1).float().div(255))
+
+
+def test_header_layout():
+    # qarv/model.py:525-528,567: '2H'(h,w) | 'f'(lambda) | '3H'(nB,H/64,W/64) | 'B'(9) | '9I' | payload -> 51 bytes overhead
+    body = struct.pack('f', 2048.0) + struct.pack('3H', 1, 8, 12) + coding.pack_byte_strings([b''] * 9)
+    assert len(struct.pack('2H', 512, 768) + body) == 51
