@@ -201,6 +201,8 @@ def main():
                 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
                 'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3)}
 
+    if rank == 0 and model.timing is not None:
+        print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)
     if rank == 0:
         px = world * B * H * W * args.steps
         line = {

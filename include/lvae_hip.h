@@ -110,8 +110,12 @@ typedef struct {
     float* out; long ldo;
     int  M, N, K;                         /* K = total reduction length */
     int  a_mode, epi, store, r;           /* r = pixel-shuffle factor */
+    int  cfg;                             /* tile configuration: 0 = library heuristic, k>0 = candidate k-1 of
+                                             lvae_gemm_num_configs() (results are bit-identical for every choice;
+                                             the Python host autotunes this per shape at plan-build time) */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
+int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
 
 /* Depthwise kxk conv (+bias) -> LayerNorm over C (eps 1e-6, biased variance, no affine) -> AdaLN
  * y*(1+scale)+shift, one pass over an NHWC map (common.py:145-152).  wt is [k*k][C] (tap-major), `ln_w`/`ln_b`
@@ -144,6 +148,9 @@ int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float*
 int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, void* stream);
 /* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order. */
 int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, void* stream);
+
+/* y = gelu_erf(x) elementwise: the exact-erf GELU used by every fused epilogue, exposed for numerics tests. */
+int lvae_gelu_f32(const float* x, float* y, long n, void* stream);
 
 /* Broadcast a [C] vector to all M rows (get_bias, qarv/model.py:289-292). */
 int lvae_bias_expand_f32(const float* bias, float* out, long M, int C, void* stream);

@@ -26,13 +26,15 @@
 //    encoder and decoder (different M) derive bit-identical priors.  No split-K, no atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lvae_hip.h"
+#include "device_math.h"
 
 #ifdef LVAE_GEMM_TRACE
 extern "C" __device__ long* lvae_trace_buf;          // [16 k-tiles][8 stamps], filled by one wave of one block
 // stamps go to LDS (beyond the tiles) so that they do not sit on the vmcnt queue the loader waits on; dumped at the end
-#define TRACE_STAMP(slot) do { if (tracing && kt < 16) ((long*)(smem + 2 * (C::BM + C::BN) * LDT))[kt * 8 + (slot)] = clock64(); } while (0)
+#define TRACE_STAMP(slot) do { if (tracing && kt < 16) ((long*)(smem + C::NBUF * (C::BM + C::BN) * LDT))[kt * 8 + (slot)] = clock64(); } while (0)
 #else
 #define TRACE_STAMP(slot) do {} while (0)
 #endif
@@ -45,7 +47,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;        // k-tile
 constexpr int LDT = BK + 4;   // padded LDS row (floats)
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // 4x4 transpose across the 4 lanes of a quad with DPP quad_perm moves (lane^1: [1,0,3,2] = 0xB1, lane^2: [2,3,0,1] =
 // 0x4E): afterwards lane j holds in (v0..v3) what lanes 0..3 of its quad held in register j.  Used to turn the MFMA
@@ -65,9 +66,10 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
 }
 
-template <int WGM_, int WGN_, int TM_, int TN_>
+template <int WGM_, int WGN_, int TM_, int TN_, int NBUF_ = 2>
 struct Cfg {
     static constexpr int WGM = WGM_, WGN = WGN_, TM = TM_, TN = TN_;
+    static constexpr int NBUF = NBUF_;            // LDS stages: 2 = double-buffered (1 barrier / k-tile), 1 = single (2 barriers)
     static constexpr int NT = 64 * WGM * WGN;     // threads per workgroup (4 or 8 wave64)
     static constexpr int BM = WGM * TM * 32;
     static constexpr int BN = WGN * TN * 32;
@@ -75,9 +77,9 @@ struct Cfg {
     static constexpr int NA = (BM + RP - 1) / RP; // float4 loads per thread per k-tile (A)
     static constexpr int NB = (BN + RP - 1) / RP; // (W)
 #ifdef LVAE_GEMM_TRACE
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDT * 4 + 1024;
+    static constexpr int LDS_BYTES = NBUF * (BM + BN) * LDT * 4 + 1024;
 #else
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDT * 4;
+    static constexpr int LDS_BYTES = NBUF * (BM + BN) * LDT * 4;
 #endif
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     static_assert(BM % RP == 0, "A tile must be a whole number of staging passes");
@@ -140,8 +142,8 @@ __device__ __forceinline__ f32x4 load_a(const lvae_gemm_desc& d, const RowInfo& 
 template <class C, int AMODE>
 __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [2][BM][LDT]
-    float* Ws = smem + 2 * C::BM * LDT;        // [2][BN][LDT]
+    float* As = smem;                          // [NBUF][BM][LDT]
+    float* Ws = smem + C::NBUF * C::BM * LDT;  // [NBUF][BN][LDT]
 
     // XCD-aware bijective remap (block b runs on XCD b%8): each XCD gets a contiguous chunk of the tile list
     int t;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     const bool tracing = (blockIdx.x == gridDim.x / 2 + 3) && tid == 0;
 #endif
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (C::NBUF == 2) ? (kt & 1) : 0;
         TRACE_STAMP(0);
 #if defined(LVAE_GEMM_LOADSAME)
         if (kt + 1 < nk) gload(kt & 1);
@@ -242,14 +244,21 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
         }
         TRACE_STAMP(2);
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        TRACE_STAMP(3);
-        __syncthreads();
+        if (C::NBUF == 2) {
+            if (kt + 1 < nk) lstore(cur ^ 1);
+            TRACE_STAMP(3);
+            __syncthreads();
+        } else if (kt + 1 < nk) {
+            __syncthreads();                    // every wave has finished reading the (only) stage
+            lstore(0);
+            TRACE_STAMP(3);
+            __syncthreads();
+        }
         TRACE_STAMP(4);
     }
 
 #ifdef LVAE_GEMM_TRACE
-    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + 2 * (C::BM + C::BN) * LDT))[i];
+    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + C::NBUF * (C::BM + C::BN) * LDT))[i];
 #endif
     // ---------------------------------------------------------------- epilogue
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -396,8 +405,14 @@ typedef Cfg<4, 2, 2, 4> CfgL256;   // 256 x 256, wave 64x128
 typedef Cfg<4, 2, 2, 3> CfgL192;   // 256 x 192, wave 64x96
 typedef Cfg<8, 1, 1, 7> CfgL224;   // 256 x 224, wave 32x224  (N = 448 = 1.75 x 256)
 typedef Cfg<4, 2, 2, 2> CfgL128;   // 256 x 128, wave 64x64
+// 4-wave single-LDS-stage configs, 2 workgroups per CU (one wave of each per SIMD): the co-resident workgroup's main
+// loop covers this one's prologue / epilogue / barriers -- for the short-K layers (K = 128..768) where a 1-per-CU tile
+// spends a third of its life outside the MFMA loop.
+typedef Cfg<2, 2, 2, 4, 1> CfgD256;   // 128 x 256, wave 64x128, 55 KB LDS
+typedef Cfg<2, 2, 2, 3, 1> CfgD192;   // 128 x 192, wave 64x96,  46 KB LDS
 
 constexpr int kCUs = 256;
+int g_force_cfg = -1;      // tuning hook (LVAE_GEMM_CFG env var): force a tile configuration id for N > 64
 
 // Estimated cost (arbitrary units ~ MFMA cycles on the critical CU) of running the problem with a BMxBN tile:
 // rounds of tiles over the CUs (workgroup slots) x per-tile work, plus a per-tile fixed cost (prologue + epilogue).
@@ -412,8 +427,10 @@ inline double tile_cost(int M, int N, int K, int BM, int BN, int wg_per_cu, doub
 template <int AMODE>
 int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     const int N = d->N, M = d->M, K = d->K;
-    if (N <= 32 || N == 96) return launch_cfg<CfgC, AMODE>(d, st);
-    if (N <= 64) return launch_cfg<CfgB, AMODE>(d, st);
+    if (d->cfg <= 0 && g_force_cfg < 0) {
+        if (N <= 32 || N == 96) return launch_cfg<CfgC, AMODE>(d, st);
+        if (N <= 64) return launch_cfg<CfgB, AMODE>(d, st);
+    }
     // candidates: {cost, id}; eff = measured relative MFMA efficiency of the structure
     double best = 1e300;
     int id = 0;
@@ -428,6 +445,8 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     consider(4, 256, 192, 1, 0.88);
     consider(5, 256, 224, 1, 0.85);
     consider(6, 256, 128, 1, 0.85);
+    if (g_force_cfg >= 0) id = g_force_cfg;
+    if (d->cfg > 0) id = d->cfg - 1;
     switch (id) {
         case 0: return launch_cfg<CfgA, AMODE>(d, st);
         case 1: return launch_cfg<CfgB, AMODE>(d, st);
@@ -435,13 +454,20 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
         case 3: return launch_cfg<CfgL256, AMODE>(d, st);
         case 4: return launch_cfg<CfgL192, AMODE>(d, st);
         case 5: return launch_cfg<CfgL224, AMODE>(d, st);
+        case 7: return launch_cfg<CfgD256, AMODE>(d, st);
+        case 8: return launch_cfg<CfgD192, AMODE>(d, st);
+        case 9: return launch_cfg<CfgC, AMODE>(d, st);
         default: return launch_cfg<CfgL128, AMODE>(d, st);
     }
 }
 
 }  // namespace
 
+extern "C" int lvae_gemm_num_configs(void) { return 10; }
+
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e); env_read = true; }
     if (!d || !d->A0 || !d->Wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
     if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;

@@ -14,12 +14,12 @@
 #include <stdint.h>
 
 #include "../../include/lvae_hip.h"
+#include "device_math.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ------------------------------------------------------------------------------------------------ dwconv + LN + AdaLN
 // A wave64 is split into 64/LPP pixel groups; each group of LPP lanes owns TW consecutive output pixels of one image
@@ -376,5 +376,18 @@ extern "C" int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, i
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 1; }
+namespace {
+__global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = gelu_erf(x[i]);
+}
+}  // namespace
+
+extern "C" int lvae_gelu_f32(const float* x, float* y, long n, void* stream) {
+    if (!x || !y || n <= 0) return -22;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_abi_version(void) { return 2; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -25,6 +25,7 @@ class GemmDesc(C.Structure):
         ('out', C.c_void_p), ('ldo', C.c_long),
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
+        ('cfg', C.c_int),
     ]
 
 
@@ -44,6 +45,8 @@ SIGNATURES = {
     'lvae_rans_encode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     'lvae_rans_decode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     'lvae_gemm_f32': (_i, [C.POINTER(GemmDesc), _vp]),
+    'lvae_gemm_num_configs': (_i, []),
+    'lvae_gelu_f32': (_i, [_vp, _vp, _l, _vp]),
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -6,6 +6,7 @@ This is the MI355X-side replacement for the reference's eager `nn.Module.forward
 ~10^3 elementwise kernels per encode: SURVEY.md 8(a) A15).  PyTorch is used only as the allocator / stream owner.
 """
 import ctypes
+import os
 
 import torch
 
@@ -13,7 +14,49 @@ from . import _native
 from ._native import GemmDesc
 
 
+# tile configurations of lvae_gemm_f32 (index = cfg-1): (BM, BN) -- used only to prune autotune candidates
+_GEMM_TILES = [(128, 128), (128, 64), (64, 64), (256, 256), (256, 192), (256, 224), (256, 128), (128, 256), (128, 192), (128, 32)]
+_TUNE_CACHE = {}
+
+
+def autotune_gemm(lib, d, stream_ptr, device):
+    """Pick the fastest tile configuration for this GEMM shape by timing the candidates on the GPU (2 timed runs each
+    after a warm-up).  Every configuration produces bit-identical results (fixed k-order), so this only affects speed."""
+    key = (d.M, d.N, d.K, d.K0, d.K1, d.a_mode, d.epi, d.store)
+    best = _TUNE_CACHE.get(key)
+    if best is not None:
+        return best
+    cands = []
+    for i, (bm, bn) in enumerate(_GEMM_TILES):
+        if bn >= 2 * d.N and bn > 32:          # more than half of the tile's columns would be padding
+            continue
+        if d.N > 4 * bn and bn <= 64:          # narrow tiles on a wide problem
+            continue
+        if bm >= 4 * d.M and bm > 64:
+            continue
+        cands.append(i + 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(device)
+    best, best_t = 0, float('inf')
+    for c in cands:
+        d.cfg = c
+        if lib.lvae_gemm_f32(ctypes.byref(d), stream_ptr) != 0:
+            continue
+        e0.record(st)
+        for _ in range(2):
+            lib.lvae_gemm_f32(ctypes.byref(d), stream_ptr)
+        e1.record(st)
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = c, t
+    _TUNE_CACHE[key] = best
+    return best
+
+
 class Plan:
+    autotune = os.environ.get('LVAE_AUTOTUNE', '0') == '1'    # opt-in: in-situ gains were within noise (DESIGN.md 5)
+
     def __init__(self, device):
         self.lib = _native.lib()
         self.device = torch.device(device)
@@ -59,6 +102,10 @@ class Plan:
         d.out, d.ldo = out, (ldo if ldo is not None else N)
         d.M, d.N, d.K = M, N, K
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
+        d.cfg = 0
+        if self.autotune and M * N >= 64 * 64:
+            sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            d.cfg = autotune_gemm(self.lib, d, sp, self.device)
         self.keep.append(d)
         self.flops += 2 * M * N * K
         self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)

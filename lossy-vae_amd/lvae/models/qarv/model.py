@@ -12,7 +12,9 @@ record the whole network as native HIP launches (lvae/engine.py).  Extension ove
 rANS streams of the B images x 9 latent blocks are coded by parallel host threads.
 """
 import math
+import os
 import struct
+import time
 
 import numpy as np
 import torch
@@ -407,10 +409,15 @@ class VariableRateLossyVAE(nn.Module):
         self.register_buffer('_dummy', torch.zeros(1), persistent=False)
         self.compressing = False
         self.coder_threads = 0          # 0 = all hardware threads
+        self.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))   # a batch is split into this many groups, each on its own HIP stream + host thread,
+                                        # so that one group's host rANS overlaps the other group's GPU work
+        self._streams = []
+        self._pool = None
         self._packed = None
         self._packed_key = None
         self._plans = {}
         self._cur_lmb = None
+        self.timing = {} if os.environ.get('LVAE_TIMING') else None      # host-side phase timers (debug)
 
     # ---- helpers
     def _dg(self) -> DiscretizedGaussian:
@@ -466,8 +473,8 @@ class VariableRateLossyVAE(nn.Module):
                                         pk.adaln_total, self.lmb_embed_dim[1], 1, 0, st), 'gemv adaln')
         self._cur_lmb = lmb
 
-    def _plan(self, kind, B, a, b):
-        key = (kind, B, a, b)
+    def _plan(self, kind, B, a, b, group=0):
+        key = (kind, B, a, b, group)
         pl = self._plans.get(key)
         if pl is None:
             pk = self._prepare()
@@ -491,6 +498,44 @@ class VariableRateLossyVAE(nn.Module):
                         dg._host = None
         self.compressing = mode
 
+    def _groups(self, B):
+        """Split a batch of B into contiguous groups [(start, size)] for the stream/thread pipeline."""
+        G = max(1, min(int(self.pipeline_groups), B))
+        if B < 4:
+            G = 1
+        base, rem = divmod(B, G)
+        out, o = [], 0
+        for g in range(G):
+            n = base + (1 if g < rem else 0)
+            out.append((o, n))
+            o += n
+        return out
+
+    def _run_groups(self, fn, groups):
+        """Run fn(g, start, size, stream) for every group: inline for one group, else one host thread + HIP stream each."""
+        dev = self._dummy.device
+        if len(groups) == 1:
+            return [fn(0, groups[0][0], groups[0][1], torch.cuda.current_stream(dev))]
+        while len(self._streams) < len(groups):
+            self._streams.append(torch.cuda.Stream(device=dev))
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=8)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))        # lambda tables / inputs produced on the caller's stream
+
+        def work(g):
+            st = self._streams[g]
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                return fn(g, groups[g][0], groups[g][1], st)
+        futs = [self._pool.submit(work, g) for g in range(len(groups))]
+        res = [f.result() for f in futs]
+        cur = torch.cuda.current_stream(dev)
+        for g in range(len(groups)):                      # caller's stream sees the groups' results
+            cur.wait_stream(self._streams[g])
+        return res
+
     @torch.no_grad()
     def compress_batch(self, im, lmb=None):
         """Encode a (B,3,H,W) batch -> list of B byte strings (each identical to `compress(im[b:b+1])`)."""
@@ -500,25 +545,40 @@ class VariableRateLossyVAE(nn.Module):
         assert (H % self.max_stride == 0) and (W % self.max_stride == 0), f'{im.shape=}'
         self._prepare()
         self._set_lmb(lmb)
-        pl = self._plan('enc', B, H, W)
-        pl.im.view(B, 3, H, W).copy_(im)
-        pl.run()
-        pl.sym_host.copy_(pl.sym_all, non_blocking=True)
-        pl.idx_host.copy_(pl.idx_all, non_blocking=True)
-        torch.cuda.current_stream(pl.device).synchronize()
         tables = self._dg().host_tables()
-        sv, iv = [], []
-        for b in range(B):
-            for li, (z, hw) in enumerate(pl.lat_shapes):
-                o = pl.sym_off[li] + b * z * hw
-                sv.append(pl.sym_np[o:o + z * hw]); iv.append(pl.idx_np[o:o + z * hw])
-        strings = rans_encode_streams(tables, sv, iv, self.coder_threads)
-        nl = len(pl.lat_shapes)
-        assert nl == self.num_latents
-        out = []
         header = struct.pack('f', lmb) + struct.pack('3H', 1, H // self.max_stride, W // self.max_stride)
-        for b in range(B):
-            out.append(header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]))
+        groups = self._groups(B)
+        nthreads = self.coder_threads if len(groups) == 1 else max(1, (self.coder_threads or (os.cpu_count() or 8)) // len(groups))
+        T = self.timing
+
+        def encode_group(g, start, n, stream):
+            pl = self._plan('enc', n, H, W, g)
+            t0 = time.time()
+            pl.im.view(n, 3, H, W).copy_(im[start:start + n])
+            pl.run(stream=stream.cuda_stream)
+            t1 = time.time()
+            pl.sym_host.copy_(pl.sym_all, non_blocking=True)
+            pl.idx_host.copy_(pl.idx_all, non_blocking=True)
+            stream.synchronize()
+            t2 = time.time()
+            sv, iv = [], []
+            for b in range(n):
+                for li, (z, hw) in enumerate(pl.lat_shapes):
+                    o = pl.sym_off[li] + b * z * hw
+                    sv.append(pl.sym_np[o:o + z * hw]); iv.append(pl.idx_np[o:o + z * hw])
+            strings = rans_encode_streams(tables, sv, iv, nthreads)
+            if T is not None:
+                t3 = time.time()
+                T['enc_launch'] = T.get('enc_launch', 0) + t1 - t0
+                T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + t2 - t1
+                T['enc_rans'] = T.get('enc_rans', 0) + t3 - t2
+            nl = len(pl.lat_shapes)
+            assert nl == self.num_latents
+            return [header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]) for b in range(n)]
+
+        out = []
+        for part in self._run_groups(encode_group, groups):
+            out += part
         return out
 
     @torch.no_grad()
@@ -537,24 +597,39 @@ class VariableRateLossyVAE(nn.Module):
         lv = [coding.unpack_byte_string(s[10:]) for s in strings]
         self._prepare()
         self._set_lmb(lmb)
-        pl = self._plan('dec', B, nH, nW)
-        assert all(len(x) == len(pl.cuts) for x in lv), f'expected {len(pl.cuts)} strings per image'
         tables = self._dg().host_tables()
-        stream = torch.cuda.current_stream(pl.device)
-        lo = 0
-        for li, cut in enumerate(pl.cuts):
-            pl.run(lo, cut)
-            lo = cut
-            z, hw = pl.lat_shapes[li]
-            o, n = pl.idx_off[li], B * z * hw
-            pl.idx_host[o:o + n].copy_(pl.idx_all[o:o + n], non_blocking=True)
-            stream.synchronize()
-            iv = [pl.idx_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(B)]
-            sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(B)]
-            rans_decode_streams(tables, [lv[b][li] for b in range(B)], iv, sv, self.coder_threads)
-            pl.sym_all[o:o + n].copy_(pl.sym_host[o:o + n], non_blocking=True)
-        pl.run(lo, None)
-        return pl.out.clone()
+        groups = self._groups(B)
+        nthreads = self.coder_threads if len(groups) == 1 else max(1, (self.coder_threads or (os.cpu_count() or 8)) // len(groups))
+        T = self.timing
+        out = torch.empty(B, 3, nH * self.max_stride, nW * self.max_stride, device=self._dummy.device)
+
+        def decode_group(g, start, n, stream):
+            pl = self._plan('dec', n, nH, nW, g)
+            assert all(len(lv[start + b]) == len(pl.cuts) for b in range(n)), f'expected {len(pl.cuts)} strings per image'
+            lo = 0
+            for li, cut in enumerate(pl.cuts):
+                t0 = time.time()
+                pl.run(lo, cut, stream=stream.cuda_stream)
+                lo = cut
+                z, hw = pl.lat_shapes[li]
+                o, cnt = pl.idx_off[li], n * z * hw
+                pl.idx_host[o:o + cnt].copy_(pl.idx_all[o:o + cnt], non_blocking=True)
+                stream.synchronize()
+                t1 = time.time()
+                iv = [pl.idx_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
+                sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
+                rans_decode_streams(tables, [lv[start + b][li] for b in range(n)], iv, sv, nthreads)
+                pl.sym_all[o:o + cnt].copy_(pl.sym_host[o:o + cnt], non_blocking=True)
+                if T is not None:
+                    t2 = time.time()
+                    T['dec_gpu_seg'] = T.get('dec_gpu_seg', 0) + t1 - t0
+                    T['dec_rans'] = T.get('dec_rans', 0) + t2 - t1
+            pl.run(lo, None, stream=stream.cuda_stream)
+            out[start:start + n].copy_(pl.out, non_blocking=True)
+            return None
+
+        self._run_groups(decode_group, groups)
+        return out
 
     @torch.no_grad()
     def decompress(self, string):

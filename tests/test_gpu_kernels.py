@@ -272,3 +272,14 @@ def test_sqerr(L):
     torch.cuda.synchronize()
     ref = (a.double() - b.double()).square().sum(1)
     assert torch.allclose(out, ref, rtol=1e-6)   # kernel forms a-b in fp32 (as the reference does) then accumulates in fp64
+
+
+def test_gelu_erf_accuracy(L):
+    """The fused epilogues' exact-erf GELU (csrc/device_math.h) vs fp64: |err| <= 2e-7 * max(1,|x|) on a dense grid."""
+    x = torch.cat([torch.linspace(-8, 8, 400001), torch.linspace(-1.5, 1.5, 200001)]).cuda()
+    y = torch.empty_like(x)
+    assert L.lvae_gelu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _st()) == 0
+    torch.cuda.synchronize()
+    ref = F.gelu(x.double())
+    err = (y.double() - ref).abs() / torch.clamp(x.double().abs(), min=1.0)
+    assert float(err.max()) <= 2e-7, float(err.max())
