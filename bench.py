@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(REPO, 'lossy-vae_amd'))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+PROFILE = os.environ.get('LVAE_BENCH_PROFILE', 'typical')   # seeded-weight profile (lossy-vae_amd/seeded_init.py)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
@@ -35,7 +36,7 @@ def build_model(device):
     m = lvae.get_model('qarv_base')
     sd = m.state_dict()
     for k in list(sd.keys()):
-        a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0)
+        a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0, profile=PROFILE)
         if a is not None:
             sd[k] = torch.from_numpy(a)
     m.load_state_dict(sd)
@@ -210,7 +211,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
-                                   f'fp32 HIP kernels + host rANS, seeded random-init weights', 'global_batch': world * B,
+                                   f'fp32 HIP kernels + host rANS, seeded random-init weights (profile {PROFILE})', 'global_batch': world * B,
                        'parallelism': f'dp{world} (images sharded, no data-path collective)',
                        'lambda': model.default_lmb},
             'enc_ms_per_step': round(t_enc / args.steps * 1e3, 3),

@@ -21,8 +21,16 @@ def _rng(name, seed):
     return np.random.Generator(np.random.Philox(key=key))
 
 
-def seeded_tensor(name, shape, seed=0):
+# 'wide'    : posterior x8 / prior x4 -- symbols span roughly +-20, scale indexes cover all 64 rows, ~11% of the symbols
+#             take the coder's bypass escape, ~11 bpp.  Used by the parity tests / golden fixtures (stresses every path).
+# 'typical' : posterior x1 / prior x1 -- ~2.5 bpp, no escapes: the coder load of a trained model at lambda=2048
+#             (reference Kodak: 2.21 bpp, results/kodak/kodak-qarv_base.json).  Used by bench.py; GPU work is identical.
+PROFILES = {'wide': (8.0, 4.0), 'typical': (1.0, 1.0)}
+
+
+def seeded_tensor(name, shape, seed=0, profile='wide'):
     """numpy float32 array for one state-dict entry, or None if the entry is a derived buffer."""
+    post_scale, prior_scale = PROFILES[profile]
     if any(s in name for s in _SKIP):
         return None
     shape = tuple(int(s) for s in shape)
@@ -41,19 +49,19 @@ def seeded_tensor(name, shape, seed=0):
         b = 1.0 / np.sqrt(fan_in)
         a = g.uniform(-b, b, size=shape)
         if name.endswith('.posterior.weight') or '.posterior.c4.' in name:
-            a *= 8.0
+            a *= post_scale
         if name.endswith('.prior.weight') or '.prior.c4.' in name:
-            a *= 4.0
+            a *= prior_scale
     else:
         a = g.normal(0.0, 0.05, size=shape)
     return a.astype(np.float32)
 
 
-def seeded_state_dict(named_shapes, seed=0):
+def seeded_state_dict(named_shapes, seed=0, profile='wide'):
     """named_shapes: iterable of (name, shape).  Returns {name: np.float32 array} for parameter entries."""
     out = {}
     for name, shape in named_shapes:
-        a = seeded_tensor(name, shape, seed)
+        a = seeded_tensor(name, shape, seed, profile)
         if a is not None:
             out[name] = a
     return out
