@@ -110,6 +110,8 @@ typedef struct {
     float* out; long ldo;
     int  M, N, K;                         /* K = total reduction length */
     int  a_mode, epi, store, r;           /* r = pixel-shuffle factor */
+    int  a_gelu;                          /* 1: apply gelu_erf to every A element on load (VDBlock's c1(gelu(x)),
+                                             lvae/models/qresvae/model.py:143-144) */
     int  cfg;                             /* tile configuration: 0 = library heuristic, k>0 = candidate k-1 of
                                              lvae_gemm_num_configs() (results are bit-identical for every choice;
                                              the Python host autotunes this per shape at plan-build time) */
@@ -144,10 +146,13 @@ int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float*
                          float scale_bound, int B, int HW, int z, void* stream);
 
 /* GaussianConditional.quantize (qarv/model.py:107-108): sym = int32(rint_half_even(qm - pm)) in NCHW raster order
- * per image, zhat = float(sym) + pm in NHWC. */
-int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, void* stream);
-/* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order. */
-int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, void* stream);
+ * per image, zhat = float(sym) + pm in NHWC (row stride ldz, see below). */
+int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
+                      void* stream);
+/* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order.
+ * In both, zhat rows have stride ldz >= z floats; columns [z, ldz) are written as zeros (lets a following 3x3 conv
+ * consume a channel count rounded up to a multiple of 4: qres34m z = 14, 10). */
+int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz, void* stream);
 
 /* y = gelu_erf(x) elementwise: the exact-erf GELU used by every fused epilogue, exposed for numerics tests. */
 int lvae_gelu_f32(const float* x, float* y, long n, void* stream);

@@ -203,7 +203,11 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
         float* a = As + buf * C::BM * LDT + srow * LDT + sk4 * 4;
         float* w = Ws + buf * C::BN * LDT + srow * LDT + sk4 * 4;
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) *(f32x4*)(a + C::RP * i * LDT) = ((okmask >> i) & 1u) ? ra[i] : zero4;
+        for (int i = 0; i < C::NA; ++i) {
+            f32x4 v = ((okmask >> i) & 1u) ? ra[i] : zero4;
+            if (d.a_gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            *(f32x4*)(a + C::RP * i * LDT) = v;
+        }
 #pragma unroll
         for (int i = 0; i < C::NB; ++i)
             if (C::BN % C::RP == 0 || srow + C::RP * i < C::BN)

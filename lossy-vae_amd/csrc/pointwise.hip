@@ -251,13 +251,14 @@ __global__ void prior_index_kernel(const float* __restrict__ prm, float* __restr
 }
 
 __global__ void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
-                                float* __restrict__ zhat, long total, int HW, int z) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                float* __restrict__ zhat, long total, int HW, int z, int ldz) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*ldz + c over the PADDED rows
     if (e >= total) return;
-    const long m = e / z;
-    const int c = (int)(e - m * z);
-    const float mu = pm[e];
-    const float r = rintf(qm[e] - mu);          // v_rndne_f32: round-half-to-even == torch.round
+    const long m = e / ldz;
+    const int c = (int)(e - m * ldz);
+    if (c >= z) { zhat[e] = 0.f; return; }
+    const float mu = pm[m * z + c];
+    const float r = rintf(qm[m * z + c] - mu);  // v_rndne_f32: round-half-to-even == torch.round
     zhat[e] = r + mu;
     const long b = m / HW;
     const int p = (int)(m - b * HW);
@@ -265,14 +266,15 @@ __global__ void quantize_kernel(const float* __restrict__ qm, const float* __res
 }
 
 __global__ void dequantize_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ zhat,
-                                  long total, int HW, int z) {
+                                  long total, int HW, int z, int ldz) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const long m = e / z;
-    const int c = (int)(e - m * z);
+    const long m = e / ldz;
+    const int c = (int)(e - m * ldz);
+    if (c >= z) { zhat[e] = 0.f; return; }
     const long b = m / HW;
     const int p = (int)(m - b * HW);
-    zhat[e] = (float)sym[(b * z + c) * HW + p] + pm[e];
+    zhat[e] = (float)sym[(b * z + c) * HW + p] + pm[m * z + c];
 }
 
 __global__ void bias_expand_kernel(const float* __restrict__ bias, float* __restrict__ out, long total4, int C4) {
@@ -342,20 +344,21 @@ extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, c
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z,
+extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
                                  void* stream) {
-    if (!qm || !pm || !sym || !zhat || B <= 0 || HW <= 0 || z <= 0) return -22;
-    const long total = (long)B * HW * z;
+    if (!qm || !pm || !sym || !zhat || B <= 0 || HW <= 0 || z <= 0 || ldz < z) return -22;
+    const long total = (long)B * HW * ldz;
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
-                       zhat, total, HW, z);
+                       zhat, total, HW, z, ldz);
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, void* stream) {
-    if (!sym || !pm || !zhat || B <= 0 || HW <= 0 || z <= 0) return -22;
-    const long total = (long)B * HW * z;
+extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz,
+                                   void* stream) {
+    if (!sym || !pm || !zhat || B <= 0 || HW <= 0 || z <= 0 || ldz < z) return -22;
+    const long total = (long)B * HW * ldz;
     hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm,
-                       zhat, total, HW, z);
+                       zhat, total, HW, z, ldz);
     return (int)hipGetLastError();
 }
 
@@ -389,5 +392,5 @@ extern "C" int lvae_gelu_f32(const float* x, float* y, long n, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 2; }
+extern "C" int lvae_abi_version(void) { return 3; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

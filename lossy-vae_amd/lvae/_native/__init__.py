@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ('out', C.c_void_p), ('ldo', C.c_long),
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
-        ('cfg', C.c_int),
+        ('a_gelu', C.c_int), ('cfg', C.c_int),
     ]
 
 
@@ -51,8 +51,8 @@ SIGNATURES = {
     'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
-    'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
 }

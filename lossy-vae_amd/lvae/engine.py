@@ -90,7 +90,7 @@ class Plan:
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, label='gemm'):
         if K is None:
             K = K0 + K1
         d = GemmDesc()
@@ -103,6 +103,7 @@ class Plan:
         d.M, d.N, d.K = M, N, K
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
         d.cfg = 0
+        d.a_gelu = a_gelu
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             d.cfg = autotune_gemm(self.lib, d, sp, self.device)

@@ -1,0 +1,58 @@
+"""Shared host-side machinery of the codecs: batch -> pipeline groups (one HIP stream + one host thread each, so that a
+group's host rANS coding overlaps the other group's GPU work), coder thread budget."""
+import os
+
+import torch
+import torch.nn as nn
+
+
+class CodecBase(nn.Module):
+    def _init_codec_base(self):
+        self.coder_threads = 0          # 0 = all hardware threads
+        self.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+        self._streams = []
+        self._pool = None
+
+    def _coder_threads_per_group(self, n_groups):
+        if n_groups == 1:
+            return self.coder_threads
+        return max(1, (self.coder_threads or (os.cpu_count() or 8)) // n_groups)
+
+    def _groups(self, B):
+        """Split a batch of B into contiguous groups [(start, size)] for the stream/thread pipeline."""
+        G = max(1, min(int(self.pipeline_groups), B))
+        if B < 4:
+            G = 1
+        base, rem = divmod(B, G)
+        out, o = [], 0
+        for g in range(G):
+            n = base + (1 if g < rem else 0)
+            out.append((o, n))
+            o += n
+        return out
+
+    def _run_groups(self, fn, groups):
+        """Run fn(g, start, size, stream) for every group: inline for one group, else one host thread + HIP stream each."""
+        dev = self._dummy.device
+        if len(groups) == 1:
+            return [fn(0, groups[0][0], groups[0][1], torch.cuda.current_stream(dev))]
+        while len(self._streams) < len(groups):
+            self._streams.append(torch.cuda.Stream(device=dev))
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=8)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))        # lambda tables / inputs produced on the caller's stream
+
+        def work(g):
+            st = self._streams[g]
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                return fn(g, groups[g][0], groups[g][1], st)
+        futs = [self._pool.submit(work, g) for g in range(len(groups))]
+        res = [f.result() for f in futs]
+        cur = torch.cuda.current_stream(dev)
+        for g in range(len(groups)):                      # caller's stream sees the groups' results
+            cur.wait_stream(self._streams[g])
+        return res
+

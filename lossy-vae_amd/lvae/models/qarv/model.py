@@ -23,6 +23,7 @@ import torch.nn as nn
 from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
+from ..base import CodecBase
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 
 EMBED_DIM = 256
@@ -328,7 +329,7 @@ class _EncPlan(_NetPlan):
                 zhat = self.buf('zhat', M * z)
                 self.sym_off.append(ioff)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
-                                                 B, h * w, z), p + '.quantize')
+                                                 B, h * w, z, z), p + '.quantize')
                 self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
             elif m.kind == 'cnx':
                 self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
@@ -362,7 +363,7 @@ class _DecPlan(_NetPlan):
                 self.cuts.append(len(self.ops))
                 self.sym_off.append(ioff)
                 zhat = self.buf('zhat', M * z)
-                self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z),
+                self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z, z),
                          p + '.dequantize')
                 self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
             elif m.kind == 'cnx':
@@ -382,7 +383,7 @@ class _DecPlan(_NetPlan):
 
 
 # ----------------------------------------------------------------------------------------------- the model
-class VariableRateLossyVAE(nn.Module):
+class VariableRateLossyVAE(CodecBase):
     log2_e = math.log2(math.e)
     MAX_LMB = 8192
 
@@ -408,11 +409,7 @@ class VariableRateLossyVAE(nn.Module):
         self.max_stride = config['max_stride']
         self.register_buffer('_dummy', torch.zeros(1), persistent=False)
         self.compressing = False
-        self.coder_threads = 0          # 0 = all hardware threads
-        self.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))   # a batch is split into this many groups, each on its own HIP stream + host thread,
-                                        # so that one group's host rANS overlaps the other group's GPU work
-        self._streams = []
-        self._pool = None
+        self._init_codec_base()
         self._packed = None
         self._packed_key = None
         self._plans = {}
@@ -498,44 +495,6 @@ class VariableRateLossyVAE(nn.Module):
                         dg._host = None
         self.compressing = mode
 
-    def _groups(self, B):
-        """Split a batch of B into contiguous groups [(start, size)] for the stream/thread pipeline."""
-        G = max(1, min(int(self.pipeline_groups), B))
-        if B < 4:
-            G = 1
-        base, rem = divmod(B, G)
-        out, o = [], 0
-        for g in range(G):
-            n = base + (1 if g < rem else 0)
-            out.append((o, n))
-            o += n
-        return out
-
-    def _run_groups(self, fn, groups):
-        """Run fn(g, start, size, stream) for every group: inline for one group, else one host thread + HIP stream each."""
-        dev = self._dummy.device
-        if len(groups) == 1:
-            return [fn(0, groups[0][0], groups[0][1], torch.cuda.current_stream(dev))]
-        while len(self._streams) < len(groups):
-            self._streams.append(torch.cuda.Stream(device=dev))
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=8)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))        # lambda tables / inputs produced on the caller's stream
-
-        def work(g):
-            st = self._streams[g]
-            st.wait_event(ev)
-            with torch.cuda.stream(st):
-                return fn(g, groups[g][0], groups[g][1], st)
-        futs = [self._pool.submit(work, g) for g in range(len(groups))]
-        res = [f.result() for f in futs]
-        cur = torch.cuda.current_stream(dev)
-        for g in range(len(groups)):                      # caller's stream sees the groups' results
-            cur.wait_stream(self._streams[g])
-        return res
-
     @torch.no_grad()
     def compress_batch(self, im, lmb=None):
         """Encode a (B,3,H,W) batch -> list of B byte strings (each identical to `compress(im[b:b+1])`)."""
@@ -548,7 +507,7 @@ class VariableRateLossyVAE(nn.Module):
         tables = self._dg().host_tables()
         header = struct.pack('f', lmb) + struct.pack('3H', 1, H // self.max_stride, W // self.max_stride)
         groups = self._groups(B)
-        nthreads = self.coder_threads if len(groups) == 1 else max(1, (self.coder_threads or (os.cpu_count() or 8)) // len(groups))
+        nthreads = self._coder_threads_per_group(len(groups))
         T = self.timing
 
         def encode_group(g, start, n, stream):
@@ -599,7 +558,7 @@ class VariableRateLossyVAE(nn.Module):
         self._set_lmb(lmb)
         tables = self._dg().host_tables()
         groups = self._groups(B)
-        nthreads = self.coder_threads if len(groups) == 1 else max(1, (self.coder_threads or (os.cpu_count() or 8)) // len(groups))
+        nthreads = self._coder_threads_per_group(len(groups))
         T = self.timing
         out = torch.empty(B, 3, nH * self.max_stride, nW * self.max_stride, device=self._dummy.device)
 

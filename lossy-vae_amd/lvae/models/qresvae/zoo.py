@@ -1,0 +1,39 @@
+"""QRes-VAE model zoo (reference: lvae/models/qresvae/zoo.py:9-60): `qres34m`, 34.0 M parameters, one model per lambda
+in {16, 32, ..., 2048}, 12 latent blocks with z = 16 | 14,14 | 12,12,12 | 10,10,10 | 8,8,8 at strides 64 ... 4."""
+import torch
+
+from ..registry import register_model
+from ..qarv.model import UpParams
+from . import model as qres
+
+_LAMBDAS = {16, 32, 64, 128, 256, 512, 1024, 2048}
+
+
+@register_model
+def qres34m(lmb=32, pretrained=False):
+    ch = 96
+    enc_nums, dec_nums, z_dims = [6, 6, 6, 4, 2], [1, 2, 3, 3, 3], [16, 14, 12, 10, 8]
+    enc_k, dec_k = [7, 7, 5, 3, 1], [1, 3, 5, 7, 7]
+    enc_w = [ch * 2, ch * 4, ch * 4, ch * 4, ch * 4]
+    dec_w = [ch * 4, ch * 4, ch * 4, ch * 4, ch * 2]
+    enc = [qres.StemParams(3, enc_w[0], 4)]
+    for lvl in range(5):
+        enc += [qres.MyCNXParams(enc_w[lvl], kernel_size=enc_k[lvl]) for _ in range(enc_nums[lvl])]
+        if lvl < 4:
+            enc.append(qres.MyCNXDownParams(enc_w[lvl], enc_w[lvl + 1]))
+    dec = []
+    for lvl in range(5):
+        dec += [qres.QLBParams(dec_w[lvl], z_dims[lvl], kernel_size=dec_k[lvl]) for _ in range(dec_nums[lvl])]
+        dec.append(UpParams(dec_w[lvl], dec_w[lvl + 1], 2) if lvl < 4 else UpParams(dec_w[lvl], 3, 4))
+    cfg = dict(enc_blocks=enc, dec_blocks=dec, im_shift=-0.4546259594901961, im_scale=3.67572653978347, max_stride=64)
+    model = qres.HierarchicalVAE(cfg)
+    model.mse_lmb = float(lmb)          # MSEOutputNet(mse_lmb=lmb) carries no parameters (qresvae/model.py:97-117)
+    if (pretrained is True) and (lmb in _LAMBDAS):
+        from torch.hub import load_state_dict_from_url
+        url = f'https://huggingface.co/duanzh0/my-model-weights/resolve/main/qres34m/qres34m-lmb{lmb}.pt'
+        model.load_state_dict(load_state_dict_from_url(url)['model'])
+    elif isinstance(pretrained, str):
+        model.load_state_dict(torch.load(pretrained)['model'])
+    else:
+        assert pretrained is False, f'Invalid {pretrained=} and {lmb=}'
+    return model

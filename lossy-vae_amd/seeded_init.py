@@ -25,12 +25,14 @@ def _rng(name, seed):
 #             take the coder's bypass escape, ~11 bpp.  Used by the parity tests / golden fixtures (stresses every path).
 # 'typical' : posterior x1 / prior x1 -- ~2.5 bpp, no escapes: the coder load of a trained model at lambda=2048
 #             (reference Kodak: 2.21 bpp, results/kodak/kodak-qarv_base.json).  Used by bench.py; GPU work is identical.
-PROFILES = {'wide': (8.0, 4.0), 'typical': (1.0, 1.0)}
+# third/fourth entries: the same two knobs for QRes-VAE, whose posterior / prior heads are 4-conv VDBlocks (last conv `c4`)
+# that attenuate far more than QARV's single convs.
+PROFILES = {'wide': (8.0, 4.0, 300.0, 60.0), 'typical': (1.0, 1.0, 40.0, 20.0)}
 
 
 def seeded_tensor(name, shape, seed=0, profile='wide'):
     """numpy float32 array for one state-dict entry, or None if the entry is a derived buffer."""
-    post_scale, prior_scale = PROFILES[profile]
+    post_scale, prior_scale, post_c4, prior_c4 = PROFILES[profile]
     if any(s in name for s in _SKIP):
         return None
     shape = tuple(int(s) for s in shape)
@@ -48,10 +50,14 @@ def seeded_tensor(name, shape, seed=0, profile='wide'):
         fan_in = int(np.prod(shape[1:]))
         b = 1.0 / np.sqrt(fan_in)
         a = g.uniform(-b, b, size=shape)
-        if name.endswith('.posterior.weight') or '.posterior.c4.' in name:
+        if name.endswith('.posterior.weight'):
             a *= post_scale
-        if name.endswith('.prior.weight') or '.prior.c4.' in name:
+        elif name.endswith('.prior.weight'):
             a *= prior_scale
+        elif '.posterior.c4.' in name:
+            a *= post_c4
+        elif '.prior.c4.' in name:
+            a *= prior_c4
     else:
         a = g.normal(0.0, 0.05, size=shape)
     return a.astype(np.float32)

@@ -186,7 +186,70 @@ def golden_imcoding(model):
     print('imcoding', res)
 
 
+@torch.no_grad()
+def golden_qres(model, h, w, tag, img_seed=0):
+    """qres34m (qresvae/model.py:649-725): per-block indexes/symbols/strings, reconstruction, pickle container size."""
+    import pickle
+    im, _ = image_tensor(h, w, img_seed)
+    out = {'hw': np.array([h, w]), 'img_seed': np.array(img_seed)}
+    recs, hooks = [], []
+    for blk in model.decoder.dec_blocks:
+        if hasattr(blk, 'discrete_gaussian'):
+            dg = blk.discrete_gaussian
+            rec = {}
+            recs.append(rec)
+
+            def mk(rec, dg):
+                orig_bi, orig_c = dg.build_indexes, dg.compress
+
+                def bi(pv):
+                    idx = orig_bi(pv)
+                    rec['pv'], rec['indexes'] = npf(pv), npf(idx).astype(np.uint8)
+                    return idx
+
+                def comp(qm, indexes, means=None):
+                    rec['pm'] = npf(means)
+                    rec['symbols'] = npf(dg.quantize(qm, 'symbols', means)).astype(np.int32)
+                    s = orig_c(qm, indexes, means=means)
+                    rec['string'] = np.frombuffer(s[0], dtype=np.uint8)
+                    return s
+                dg.build_indexes, dg.compress = bi, comp
+                return lambda: (setattr(dg, 'build_indexes', orig_bi), setattr(dg, 'compress', orig_c))
+            hooks.append(mk(rec, dg))
+    obj = model.compress(im)
+    for hk in hooks:
+        hk()
+    for bi, rec in enumerate(recs):
+        for k, v in rec.items():
+            out[f'b{bi}.{k}'] = v
+    out['smallest'] = np.array(obj[-1])
+    out['pickle_bytes'] = np.array(len(pickle.dumps(obj + [(h, w)])))
+    xhat = model.decompress(obj)
+    out['xhat'] = npf(xhat)
+    print('qres34m', tag, 'payload bytes', sum(len(r['string']) for r in recs), 'pickle', int(out['pickle_bytes']),
+          'sym range', [(int(r['symbols'].min()), int(r['symbols'].max())) for r in recs][:6],
+          'idx range', [(int(r['indexes'].min()), int(r['indexes'].max())) for r in recs][:6])
+    np.savez_compressed(os.path.join(HERE, f'qres34m_{tag}.npz'), **out)
+
+
+def main_qres():
+    model = lvae.get_model('qres34m')
+    load_seeded(model, 0)
+    model.eval()
+    model.compress_mode()
+    print('qres34m params', sum(p.numel() for p in model.parameters()) / 1e6, 'entries', len(model.state_dict()))
+    dg = model.decoder.dec_blocks[0].discrete_gaussian
+    np.savez_compressed(os.path.join(HERE, 'gaussian_conditional_tables.npz'), scale_table=npf(dg.scale_table),
+                        quantized_cdf=npf(dg._quantized_cdf), cdf_length=npf(dg._cdf_length), offset=npf(dg._offset))
+    golden_qres(model, 64, 64, '64x64')
+    golden_qres(model, 128, 192, '128x192', img_seed=1)
+    with open(os.path.join(HERE, 'qres34m_state_keys.json'), 'w') as f:
+        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'qres':
+        return main_qres()
     golden_pack()
     golden_cnx_block()
     model = lvae.get_model('qarv_base')

@@ -247,20 +247,20 @@ def test_prior_index_quantize_dequantize(L):
     # quantize / dequantize
     qm = (torch.randn(M, z, generator=g) * 6).cuda()
     sym, zhat = torch.empty(B, z, HW, dtype=torch.int32, device='cuda'), torch.empty(M, z, device='cuda')
-    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, _st()) == 0
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, z, _st()) == 0
     torch.cuda.synchronize()
     r = torch.round(qm - pm)
     assert torch.equal(sym, r.int().view(B, HW, z).permute(0, 2, 1).contiguous())
     assert torch.equal(zhat, r + pm)
     z2 = torch.empty(M, z, device='cuda')
-    assert L.lvae_dequantize_f32(sym.data_ptr(), pm.data_ptr(), z2.data_ptr(), B, HW, z, _st()) == 0
+    assert L.lvae_dequantize_f32(sym.data_ptr(), pm.data_ptr(), z2.data_ptr(), B, HW, z, z, _st()) == 0
     torch.cuda.synchronize()
     assert torch.equal(z2, zhat)
     # half-way cases: round-half-to-even
     qh = torch.tensor([[0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, 4.5]], device='cuda')
     ph = torch.zeros_like(qh)
     sh, zh = torch.empty(1, 8, 1, dtype=torch.int32, device='cuda'), torch.empty(1, 8, device='cuda')
-    assert L.lvae_quantize_f32(qh.data_ptr(), ph.data_ptr(), sh.data_ptr(), zh.data_ptr(), 1, 1, 8, _st()) == 0
+    assert L.lvae_quantize_f32(qh.data_ptr(), ph.data_ptr(), sh.data_ptr(), zh.data_ptr(), 1, 1, 8, 8, _st()) == 0
     torch.cuda.synchronize()
     assert sh.flatten().tolist() == [0, 2, 2, 0, -2, -2, 4, 4]
 
@@ -283,3 +283,39 @@ def test_gelu_erf_accuracy(L):
     ref = F.gelu(x.double())
     err = (y.double() - ref).abs() / torch.clamp(x.double().abs(), min=1.0)
     assert float(err.max()) <= 2e-7, float(err.max())
+
+
+def test_quantize_padded_rows_and_gemm_a_gelu(L):
+    """qres34m pieces: zhat rows padded to a multiple of 4 channels (z = 14 -> 16), and GELU applied to A on load."""
+    g = torch.Generator().manual_seed(8)
+    B, HW, z, ldz = 2, 15, 14, 16
+    M = B * HW
+    qm, pm = (torch.randn(M, z, generator=g) * 5).cuda(), torch.randn(M, z, generator=g).cuda()
+    sym = torch.empty(B, z, HW, dtype=torch.int32, device='cuda')
+    zhat = torch.full((M, ldz), float('nan'), device='cuda')
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, ldz, _st()) == 0
+    torch.cuda.synchronize()
+    r = torch.round(qm - pm)
+    assert torch.equal(zhat[:, :z], r + pm) and torch.equal(zhat[:, z:], torch.zeros(M, 2, device='cuda'))
+    z2 = torch.full((M, ldz), float('nan'), device='cuda')
+    assert L.lvae_dequantize_f32(sym.data_ptr(), pm.data_ptr(), z2.data_ptr(), B, HW, z, ldz, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z2, zhat)
+    # c1(gelu(cat[f, e])): two A sources + GELU on load, N = 96, then a 3x3 over 96 channels with GELU epilogue
+    Mx, K0, K1, N = 300, 384, 384, 96
+    A0, A1 = torch.randn(Mx, K0, generator=g).cuda(), torch.randn(Mx, K1, generator=g).cuda()
+    Wt = (torch.randn(N, K0 + K1, generator=g) / 27).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = torch.empty(Mx, N, device='cuda')
+    _gemm(L, A0=A0, lda0=K0, K0=K0, A1=A1, lda1=K1, K1=K1, Wt=Wt, ldw=K0 + K1, bias=b, out=out, ldo=N, M=Mx, N=N, K=K0 + K1, a_gelu=1)
+    ref = F.gelu(torch.cat([A0, A1], 1).double()) @ Wt.double().t() + b.double()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    Bc, H, W, C = 2, 5, 6, 48
+    x = torch.randn(Bc, C, H, W, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / 20).cuda()
+    bb = torch.randn(C, generator=g).cuda()
+    ref = F.gelu(F.conv2d(x.double(), w.double(), bb.double(), padding=1)).permute(0, 2, 3, 1)
+    o2 = torch.empty(Bc * H * W, C, device='cuda')
+    _gemm(L, A0=x.permute(0, 2, 3, 1).contiguous(), K0=C, H=H, W=W, Wt=w.permute(0, 2, 3, 1).reshape(C, -1).contiguous(), ldw=9 * C,
+          bias=bb, out=o2, ldo=C, M=Bc * H * W, N=C, K=9 * C, a_mode=2, epi=1)
+    assert (o2.view(Bc, H, W, C).double() - ref).abs().max().item() < 2e-5

@@ -1,0 +1,129 @@
+"""qres34m: oracle vs the reference's goldens (not-gpu) and the HIP path vs both (gpu)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import seeded_init
+from oracle import qres_oracle
+
+FLIP_BUDGET = 2e-3
+
+
+@pytest.fixture(scope='module')
+def qres_sd():
+    return seeded_init.seeded_state_dict(qres_oracle.qres_param_shapes(qres_oracle.qres34m_arch()), seed=0)
+
+
+@pytest.fixture(scope='module')
+def oracle(qres_sd):
+    o = qres_oracle.QresOracle(qres_sd)
+    o.compress_mode()
+    return o
+
+
+def _img(h, w, seed):
+    u8 = seeded_init.synthetic_image_u8(h, w, seed)
+    return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
+
+
+def test_inventory(qres_sd, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, 'qres34m_state_keys.json')))
+    params = {k: v for k, v in ref.items() if '.discrete_gaussian.' not in k}
+    assert {k: list(v.shape) for k, v in qres_sd.items()} == params
+    assert sum(v.size for v in qres_sd.values()) == 34036602           # 34.037 M
+
+
+def test_product_state_dict_and_tables(golden_dir):
+    import lvae
+    m = lvae.get_model('qres34m', lmb=64)
+    ref = json.load(open(os.path.join(golden_dir, 'qres34m_state_keys.json')))
+    assert set(m.state_dict().keys()) == set(ref.keys())
+    assert not hasattr(m, 'default_lmb')                                  # eval-var-rate.py:41 relies on this for fixed-rate models
+    m.compress_mode()
+    g = np.load(os.path.join(golden_dir, 'gaussian_conditional_tables.npz'))
+    dg = m._dg()
+    assert np.array_equal(dg._quantized_cdf.numpy(), g['quantized_cdf']) and np.array_equal(dg._offset.numpy(), g['offset'])
+    assert np.array_equal(dg._cdf_length.numpy(), g['cdf_length']) and np.array_equal(dg.scale_table.numpy(), g['scale_table'])
+    # a checkpoint saved before compress_mode() (empty buffers) or without some entropy-model buffers must load
+    sd = {k: v for k, v in lvae.get_model('qres34m').state_dict().items() if not k.endswith('scale_bound')}
+    m.load_state_dict(sd)
+
+
+@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
+def test_oracle_matches_reference(golden_dir, oracle, tag, seed):
+    g = np.load(os.path.join(golden_dir, f'qres34m_{tag}.npz'))
+    h, w = g['hw'].tolist()
+    im = _img(h, w, seed)
+    tr = oracle.encode_trace(im, code=True)
+    assert tuple(g['smallest'].tolist()) == tr['smallest']
+    n = flips = 0
+    for bi, blk in enumerate(tr['blocks']):
+        np.testing.assert_allclose(blk['pm'].numpy(), g[f'b{bi}.pm'], rtol=1e-4, atol=2e-4)
+        n += blk['symbols'].numel()
+        flips += int((blk['symbols'].numpy() != g[f'b{bi}.symbols']).sum()) + int((blk['indexes'].numpy() != g[f'b{bi}.indexes']).sum())
+        if flips == 0:
+            assert blk['strings'][0] == g[f'b{bi}.string'].tobytes()
+    assert flips <= FLIP_BUDGET * n
+    obj = oracle.compress(im)
+    assert len(pickle.dumps(obj + [(h, w)])) == int(g['pickle_bytes']) or flips
+    xhat = oracle.decompress(obj)
+    np.testing.assert_allclose(xhat.numpy(), g['xhat'], rtol=0, atol=1e-4 if flips == 0 else 5e-2)
+
+
+@pytest.fixture(scope='module')
+def product(qres_sd):
+    import lvae
+    m = lvae.get_model('qres34m')
+    full = m.state_dict()
+    for k, v in qres_sd.items():
+        full[k] = torch.from_numpy(v)
+    m.load_state_dict(full)
+    m.compress_mode()                      # eval-fix-rate.py order: tables on the CPU, then .to(device)
+    m = m.to('cuda:0').eval()
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
+def test_hip_matches_reference(golden_dir, product, tag, seed):
+    g = np.load(os.path.join(golden_dir, f'qres34m_{tag}.npz'))
+    h, w = g['hw'].tolist()
+    im = _img(h, w, seed).cuda()
+    tr = product.encode_trace(im)
+    n = flips = 0
+    for bi, blk in enumerate(tr):
+        n += blk['symbols'].size
+        flips += int((blk['symbols'].reshape(-1) != g[f'b{bi}.symbols'].reshape(-1)).sum())
+        flips += int((blk['indexes'].reshape(-1) != g[f'b{bi}.indexes'].reshape(-1)).sum())
+    print(f'qres34m {tag}: {flips} flips of {n}')
+    assert np.array_equal(tr[0]['symbols'].reshape(-1), g['b0.symbols'].reshape(-1))
+    assert flips <= FLIP_BUDGET * n
+    obj = product.compress(im)
+    assert tuple(obj[-1]) == tuple(g['smallest'].tolist()) and len(obj) == 13
+    xhat = product.decompress(obj)
+    if flips == 0:
+        for bi in range(12):
+            assert obj[bi][0] == g[f'b{bi}.string'].tobytes()
+        assert float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_file_round_trip_and_batch(product, tmp_path):
+    from PIL import Image
+    u8 = seeded_init.synthetic_image_u8(100, 70, 11)
+    Image.fromarray(u8).save(tmp_path / 'a.png')
+    product.compress_file(tmp_path / 'a.png', tmp_path / 'a.bits')
+    obj = pickle.load(open(tmp_path / 'a.bits', 'rb'))
+    assert obj[-1] == (100, 70) and obj[-2] == (1, 384, 2, 2) and len(obj) == 14
+    x = product.decompress_file(tmp_path / 'a.bits')
+    assert x.shape == (1, 3, 100, 70)
+    ims = torch.cat([_img(128, 64, s) for s in (1, 2, 3, 4, 5)], 0).cuda()
+    objs = product.compress_batch(ims)
+    for i in range(5):
+        assert objs[i] == product.compress(ims[i:i + 1])
+    xb = product.decompress_batch(objs)
+    assert torch.equal(xb[2:3], product.decompress(objs[2]))
