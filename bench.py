@@ -87,11 +87,12 @@ class KernelTimer:
         return tot, len(self.pairs)
 
 
-def cpu_baseline(sd, H, W, n_images=2):
+def cpu_baseline(sd, H, W, n_images=12, threads=16):
     """Bounded sample of the same workload on the host: oracle enc+dec of n_images 512x768 images (after 1 warm-up)."""
     from oracle import qarv_oracle
     orc = qarv_oracle.QarvOracle({k: v for k, v in sd.items()})
     orc.compress_mode()
+    torch.set_num_threads(threads)
     cores = torch.get_num_threads()
     ims = synth_batch(n_images + 1, H, W, rank=99)
     s = orc.compress(ims[0:1]); orc.decompress(s)          # warm-up
@@ -115,6 +116,8 @@ def main():
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--cpu-threads', type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -145,10 +148,7 @@ def main():
         strings, out, _ = step()
 
     timer = KernelTimer()
-    if not args.no_kernel_timing:
-        dominant = lambda label: label.endswith('.fc1') or label.endswith('.fc2')      # noqa: E731
-        for pl in model._plans.values():
-            pl.run = timer.wrap(pl, dominant)
+    dominant = lambda label: label.endswith('.fc1') or label.endswith('.fc2')      # noqa: E731
 
     def barrier():
         if dist is not None:
@@ -181,6 +181,17 @@ def main():
 
     roof = None
     if not args.no_kernel_timing:
+        # Roofline pass: the timed region above runs the product configuration (two pipeline groups on two HIP streams,
+        # whose kernels interleave on the GPU, so an event pair around one launch would also time the other stream's
+        # kernels).  The dominant kernel is therefore timed in `roofline_steps` EXTRA steps of the same workload on a
+        # single stream, every fc1/fc2 launch bracketed by HIP events on that stream.
+        model.pipeline_groups = 1
+        step()                                           # builds the single-group plans (untimed)
+        for pl in model._plans.values():
+            pl.run = timer.wrap(pl, dominant)
+        for _ in range(args.roofline_steps):
+            step()
+        torch.cuda.synchronize(dev)
         ms, n_launch = timer.summary()
         flops = 0
         for pl in model._plans.values():
@@ -189,18 +200,25 @@ def main():
         import ctypes
         from lvae._native import GemmDesc
         per_step = 0
-        for pl in model._plans.values():
+        alg_bytes = 0
+        for key, pl in model._plans.items():
+            if key[1] != B:                              # only the single-group (full batch) plans were timed
+                continue
             for fn, a, label in pl.ops:
                 if label.endswith('.fc1') or label.endswith('.fc2'):
                     d = ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
                     per_step += 2 * d.M * d.N * d.K
-        flops = per_step * args.steps
+                    alg_bytes += 4 * (d.M * d.K + d.N * d.K + d.M * d.N * (2 if d.epi in (2, 3) else 1))
+        flops = per_step * args.roofline_steps
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<*,PLAIN> (ConvNeXt MLP fc1/fc2, fp32 v_mfma_f32_32x32x2_f32)',
                 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
-                'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3)}
+                'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
+                'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
+                'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every fc1/fc2 launch',
+                'traffic_note': 'HBM bytes are collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE): profiles/'}
 
     if rank == 0 and model.timing is not None:
         print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)
@@ -221,7 +239,7 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, H, W)
+            line['cpu_baseline'] = cpu_baseline(sd, H, W, threads=args.cpu_threads)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

@@ -34,7 +34,7 @@
 #ifdef LVAE_GEMM_TRACE
 extern "C" __device__ long* lvae_trace_buf;          // [16 k-tiles][8 stamps], filled by one wave of one block
 // stamps go to LDS (beyond the tiles) so that they do not sit on the vmcnt queue the loader waits on; dumped at the end
-#define TRACE_STAMP(slot) do { if (tracing && kt < 16) ((long*)(smem + C::NBUF * (C::BM + C::BN) * LDT))[kt * 8 + (slot)] = clock64(); } while (0)
+#define TRACE_STAMP(slot) do { if (tracing && kt < 16) ((long*)(smem + C::NBUF * (C::BM + C::BN) * C::LDT))[kt * 8 + (slot)] = clock64(); } while (0)
 #else
 #define TRACE_STAMP(slot) do {} while (0)
 #endif
@@ -44,8 +44,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // k-tile
-constexpr int LDT = BK + 4;   // padded LDS row (floats)
 
 
 // 4x4 transpose across the 4 lanes of a quad with DPP quad_perm moves (lane^1: [1,0,3,2] = 0xB1, lane^2: [2,3,0,1] =
@@ -66,14 +64,17 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
 }
 
-template <int WGM_, int WGN_, int TM_, int TN_, int NBUF_ = 2>
+template <int WGM_, int WGN_, int TM_, int TN_, int NBUF_ = 2, int BK_ = 32>
 struct Cfg {
+    static constexpr int BK = BK_;                // k-tile depth (32, or 64 for the small latency-bound problems)
+    static constexpr int LDT = BK + 4;            // padded LDS row (floats): rows*LDT mod 64 distinct multiples of 4
+    static constexpr int CPR = BK / 4;            // 16-B chunks per tile row
     static constexpr int WGM = WGM_, WGN = WGN_, TM = TM_, TN = TN_;
     static constexpr int NBUF = NBUF_;            // LDS stages: 2 = double-buffered (1 barrier / k-tile), 1 = single (2 barriers)
     static constexpr int NT = 64 * WGM * WGN;     // threads per workgroup (4 or 8 wave64)
     static constexpr int BM = WGM * TM * 32;
     static constexpr int BN = WGN * TN * 32;
-    static constexpr int RP = NT / 8;             // tile rows staged per pass (8 lanes x 16 B = one 128-B row segment)
+    static constexpr int RP = NT / CPR;           // tile rows staged per pass (CPR lanes x 16 B = one row segment)
     static constexpr int NA = (BM + RP - 1) / RP; // float4 loads per thread per k-tile (A)
     static constexpr int NB = (BN + RP - 1) / RP; // (W)
 #ifdef LVAE_GEMM_TRACE
@@ -143,6 +144,7 @@ template <class C, int AMODE>
 __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [NBUF][BM][LDT]
+    constexpr int BK = C::BK, LDT = C::LDT;
     float* Ws = smem + C::NBUF * C::BM * LDT;  // [NBUF][BN][LDT]
 
     // XCD-aware bijective remap (block b runs on XCD b%8): each XCD gets a contiguous chunk of the tile list
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     const int li = lane & 31, lh = lane >> 5;
 
     // staging assignment: thread -> rows (srow + 32*i), 16-B column sk4
-    const int srow = tid >> 3, sk4 = tid & 7;
+    const int srow = tid / C::CPR, sk4 = tid % C::CPR;
     RowInfo ri[C::NA];
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) ri[i] = row_info<AMODE>(d, m0 + srow + C::RP * i);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     }
 
 #ifdef LVAE_GEMM_TRACE
-    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + C::NBUF * (C::BM + C::BN) * LDT))[i];
+    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + C::NBUF * (C::BM + C::BN) * C::LDT))[i];
 #endif
     // ---------------------------------------------------------------- epilogue
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -414,6 +416,10 @@ typedef Cfg<4, 2, 2, 2> CfgL128;   // 256 x 128, wave 64x64
 // spends a third of its life outside the MFMA loop.
 typedef Cfg<2, 2, 2, 4, 1> CfgD256;   // 128 x 256, wave 64x128, 55 KB LDS
 typedef Cfg<2, 2, 2, 3, 1> CfgD192;   // 128 x 192, wave 64x96,  46 KB LDS
+// 64-deep k-tiles for small problems (few workgroups, nothing co-resident to hide memory latency): twice the bytes in
+// flight per barrier and half the barriers -- the B=1 / stride-32,64 layers are latency-bound, not MFMA-bound.
+typedef Cfg<2, 2, 1, 1, 2, 64> CfgS64;   // 64 x 64, BK 64
+typedef Cfg<2, 2, 2, 1, 2, 64> CfgB64;   // 128 x 64, BK 64
 
 constexpr int kCUs = 256;
 int g_force_cfg = -1;      // tuning hook (LVAE_GEMM_CFG env var): force a tile configuration id for N > 64
@@ -461,13 +467,15 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
         case 7: return launch_cfg<CfgD256, AMODE>(d, st);
         case 8: return launch_cfg<CfgD192, AMODE>(d, st);
         case 9: return launch_cfg<CfgC, AMODE>(d, st);
+        case 10: return launch_cfg<CfgS64, AMODE>(d, st);
+        case 11: return launch_cfg<CfgB64, AMODE>(d, st);
         default: return launch_cfg<CfgL128, AMODE>(d, st);
     }
 }
 
 }  // namespace
 
-extern "C" int lvae_gemm_num_configs(void) { return 10; }
+extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     static bool env_read = false;

@@ -38,7 +38,15 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
     constexpr int GPW = 64 / LPP;
     constexpr int P = (KS - 1) / 2;
     const int lane = threadIdx.x & 63;
-    const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware bijective remap (workgroup b runs on XCD b%8, each XCD has its own L2): give every XCD a CONTIGUOUS band
+    // of the (image, row, column-group) space so that the k-1 halo rows a workgroup shares with its neighbours are served
+    // by the same L2.  With the round-robin default, PMC showed 3.4x the algorithmic bytes fetched from HBM.
+    long blk;
+    {
+        const long nb = gridDim.x, b = blockIdx.x, q = nb / 8, r = nb % 8, xcd = b % 8, loc = b / 8;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const long wave_g = blk * 4 + (threadIdx.x >> 6);
     const long g = wave_g * GPW + lane / LPP;
     const int cl = lane % LPP;
     const bool active = g < total_groups;

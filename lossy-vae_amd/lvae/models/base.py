@@ -34,10 +34,15 @@ class CodecBase(nn.Module):
     def _run_groups(self, fn, groups):
         """Run fn(g, start, size, stream) for every group: inline for one group, else one host thread + HIP stream each."""
         dev = self._dummy.device
-        if len(groups) == 1:
-            return [fn(0, groups[0][0], groups[0][1], torch.cuda.current_stream(dev))]
         while len(self._streams) < len(groups):
             self._streams.append(torch.cuda.Stream(device=dev))
+        if len(groups) == 1:        # inline, but still on a side stream (the legacy default stream cannot be graph-captured)
+            st, cur = self._streams[0], torch.cuda.current_stream(dev)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                res = [fn(0, groups[0][0], groups[0][1], st)]
+            cur.wait_stream(st)
+            return res
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=8)
