@@ -154,6 +154,13 @@ int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zha
  * consume a channel count rounded up to a multiple of 4: qres34m z = 14, 10). */
 int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz, void* stream);
 
+/* Eval-mode rate estimate of one latent block (qarv/model.py:95-96 = CompressAI GaussianConditional.forward in eval mode):
+ * out_nats[b] += sum over the block's elements of -ln max(P, 1e-9), P = Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s) in fp32 with
+ * s from the prior conv output `prm` as in lvae_prior_index_f32; cdf_form 0 = erf (QARV), 1 = erfc (QRes).  sym is in the
+ * coder's NCHW raster order; out_nats (double[B]) must be zeroed by the caller. */
+int lvae_gaussian_nll_f32(const float* prm, const int32_t* sym, double* out_nats, float scale_bound, int B, int HW, int z,
+                          int cdf_form, void* stream);
+
 /* y = gelu_erf(x) elementwise: the exact-erf GELU used by every fused epilogue, exposed for numerics tests. */
 int lvae_gelu_f32(const float* x, float* y, long n, void* stream);
 

@@ -285,6 +285,44 @@ __global__ void dequantize_kernel(const int32_t* __restrict__ sym, const float* 
     zhat[e] = (float)sym[(b * z + c) * HW + p] + pm[m * z + c];
 }
 
+// Eval-mode rate estimate (qarv/model.py:95-96; CompressAI GaussianConditional._likelihood): per latent element
+// P = Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), v = zhat - mean = the integer symbol, s = max(exp(softplus(x+2.3)-2.3), bound),
+// P = max(P, 1e-9); accumulates sum(-ln P) per image (nats) in fp64.  Phi in fp32 as the reference: erf form for
+// DiscretizedGaussian (underflows to exactly 0 in the tails), erfc form for stock GaussianConditional.
+__global__ __launch_bounds__(256) void gaussian_nll_kernel(const float* __restrict__ prm, const int32_t* __restrict__ sym,
+                                                           double* __restrict__ out, float bound, long per_image, int HW,
+                                                           int z, int cdf_form) {
+    const int b = blockIdx.y;
+    double acc = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per_image; e += (long)gridDim.x * 256) {
+        const long p = e / z;                    // pixel within the image
+        const int c = (int)(e - p * z);
+        const long m = (long)b * HW + p;
+        const float lv = prm[m * 2 * z + z + c];
+        const float xs = lv + 2.3f;
+        const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
+        const float s = fmaxf(expf(sp - 2.3f), bound);
+        const float v = fabsf((float)sym[((long)b * z + c) * HW + p]);
+        const float a = (0.5f - v) / s, d = (-0.5f - v) / s;
+        float up, lo;
+        if (cdf_form == 0) {
+            up = 0.5f * (1.0f + lvae_erff(a * 0.70710678118654752440f));
+            lo = 0.5f * (1.0f + lvae_erff(d * 0.70710678118654752440f));
+        } else {
+            up = 0.5f * erfcf(-0.70710678118654752440f * a);
+            lo = 0.5f * erfcf(-0.70710678118654752440f * d);
+        }
+        const float P = fmaxf(up - lo, 1e-9f);
+        acc -= (double)logf(P);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + b, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
 __global__ void bias_expand_kernel(const float* __restrict__ bias, float* __restrict__ out, long total4, int C4) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total4) return;
@@ -370,6 +408,17 @@ extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* z
     return (int)hipGetLastError();
 }
 
+extern "C" int lvae_gaussian_nll_f32(const float* prm, const int32_t* sym, double* out_nats, float scale_bound, int B, int HW,
+                                     int z, int cdf_form, void* stream) {
+    if (!prm || !sym || !out_nats || B <= 0 || HW <= 0 || z <= 0 || (cdf_form != 0 && cdf_form != 1)) return -22;
+    const long per_image = (long)HW * z;
+    long bx = (per_image + 256 * 4 - 1) / (256 * 4);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(gaussian_nll_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, sym, out_nats,
+                       scale_bound, per_image, HW, z, cdf_form);
+    return (int)hipGetLastError();
+}
+
 extern "C" int lvae_bias_expand_f32(const float* bias, float* out, long M, int C, void* stream) {
     if (!bias || !out || M <= 0 || C <= 0 || (C & 3)) return -22;
     const long total4 = M * (C / 4);
@@ -400,5 +449,5 @@ extern "C" int lvae_gelu_f32(const float* x, float* y, long n, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 3; }
+extern "C" int lvae_abi_version(void) { return 4; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -10,6 +10,8 @@ class CodecBase(nn.Module):
     def _init_codec_base(self):
         self.coder_threads = 0          # 0 = all hardware threads
         self.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+        self.enc_groups = int(os.environ.get('LVAE_ENC_GROUPS', '0'))      # 0 = use pipeline_groups
+        self.dec_groups = int(os.environ.get('LVAE_DEC_GROUPS', '0'))
         self._streams = []
         self._pool = None
 
@@ -18,9 +20,10 @@ class CodecBase(nn.Module):
             return self.coder_threads
         return max(1, (self.coder_threads or (os.cpu_count() or 8)) // n_groups)
 
-    def _groups(self, B):
+    def _groups(self, B, kind=None):
         """Split a batch of B into contiguous groups [(start, size)] for the stream/thread pipeline."""
-        G = max(1, min(int(self.pipeline_groups), B))
+        want = {'enc': self.enc_groups, 'dec': self.dec_groups}.get(kind, 0) or self.pipeline_groups
+        G = max(1, min(int(want), B))
         if B < 4:
             G = 1
         base, rem = divmod(B, G)

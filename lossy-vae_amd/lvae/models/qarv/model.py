@@ -193,6 +193,7 @@ class _NetPlan(Plan):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
+        self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
         self.lat_shapes = []                    # (z, HW)
 
     def scratch(self, M, C, hid):
@@ -230,6 +231,7 @@ class _NetPlan(Plan):
         self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
                   out=prm.data_ptr(), label=p + '.prior')
         pm = self.new(M * z)
+        self.pm_bufs.append(pm)
         ioff = sum(s[0] * s[1] for s in self.lat_shapes) * B
         self.lat_shapes.append((z, H * W))
         self.idx_off.append(ioff)
@@ -267,11 +269,12 @@ class _NetPlan(Plan):
 class _EncPlan(_NetPlan):
     """forward_end2end(mode='compress') (qarv/model.py:294-315) for B images of size HxW."""
 
-    def __init__(self, model, pk, B, H, W):
+    def __init__(self, model, pk, B, H, W, with_bits=False):
         super().__init__(model, pk, B)
         lib = self.lib
         self.im = self.new(B * 3 * H * W)
         self.alloc_latent_io(H // 64, W // 64)
+        self.nats = self.new(model.num_latents * B, torch.float64) if with_bits else None   # [block][image] sum(-ln P)
         feats = {}
         tapped = set()
         h, w = H, W
@@ -330,6 +333,10 @@ class _EncPlan(_NetPlan):
                 self.sym_off.append(ioff)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
                                                  B, h * w, z, z), p + '.quantize')
+                if with_bits:       # eval-mode likelihood of the quantised latent (qarv/model.py:95-96), prm still holds this block
+                    li = len(self.sym_off) - 1
+                    self.add(lib.lvae_gaussian_nll_f32, (self.bufs['prm'].data_ptr(), ptr(self.sym_all, ioff), ptr(self.nats, li * B),
+                                                         pk.scale_bound, B, h * w, z, 0), p + '.nll')
                 self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
             elif m.kind == 'cnx':
                 self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
@@ -475,7 +482,12 @@ class VariableRateLossyVAE(CodecBase):
         pl = self._plans.get(key)
         if pl is None:
             pk = self._prepare()
-            pl = _EncPlan(self, pk, B, a, b) if kind == 'enc' else _DecPlan(self, pk, B, a, b)
+            if kind == 'enc':
+                pl = _EncPlan(self, pk, B, a, b)
+            elif kind == 'encb':
+                pl = _EncPlan(self, pk, B, a, b, with_bits=True)
+            else:
+                pl = _DecPlan(self, pk, B, a, b)
             self._plans[key] = pl
         return pl
 
@@ -506,7 +518,7 @@ class VariableRateLossyVAE(CodecBase):
         self._set_lmb(lmb)
         tables = self._dg().host_tables()
         header = struct.pack('f', lmb) + struct.pack('3H', 1, H // self.max_stride, W // self.max_stride)
-        groups = self._groups(B)
+        groups = self._groups(B, 'enc')
         nthreads = self._coder_threads_per_group(len(groups))
         T = self.timing
 
@@ -557,7 +569,7 @@ class VariableRateLossyVAE(CodecBase):
         self._prepare()
         self._set_lmb(lmb)
         tables = self._dg().host_tables()
-        groups = self._groups(B)
+        groups = self._groups(B, 'dec')
         nthreads = self._coder_threads_per_group(len(groups))
         T = self.timing
         out = torch.empty(B, 3, nH * self.max_stride, nW * self.max_stride, device=self._dummy.device)
@@ -616,6 +628,84 @@ class VariableRateLossyVAE(CodecBase):
         img_h, img_w = struct.unpack('2H', header_str)
         im_hat = self.decompress(body_str)
         return im_hat[:, :, :img_h, :img_w]
+
+    # ---- coder-free paths
+    @torch.no_grad()
+    def estimate(self, im, lmb=None):
+        """Eval-mode forward (forward_end2end in eval mode, qarv/model.py:94-97,294-315) without entropy coding:
+        returns (im_hat (B,3,H,W) in [0,1], nats (num_latents, B) float64 = sum(-ln P) per latent block and image)."""
+        lmb = lmb or self.default_lmb
+        B, _, H, W = im.shape
+        assert (H % self.max_stride == 0) and (W % self.max_stride == 0)
+        self._prepare(); self._set_lmb(lmb)
+        enc = self._plan('encb', B, H, W)
+        dec = self._plan('dec', B, H // self.max_stride, W // self.max_stride)
+        enc.im.view(B, 3, H, W).copy_(im)
+        enc.nats.zero_()
+        enc.run()
+        # the encoder stops at CompresionStopFlag; reconstruct by feeding its symbols to the decode plan (same latent layout)
+        dec.sym_all.copy_(enc.sym_all)
+        dec.run()
+        return dec.out.clone(), enc.nats.view(self.num_latents, B).clone()
+
+    @torch.no_grad()
+    def conditional_sample(self, lmb, latents, **_):
+        """Decoder output for given latents z (qarv/model.py:365-395 with every latent provided, branch :101-103).
+        latents: list of num_latents tensors (B, z_i, h_i, w_i) on the model device whose values are integer + prior-mean,
+        i.e. exactly what the decoder reconstructs.  (Sampling missing latents from the prior is not implemented.)"""
+        assert len(latents) == self.num_latents and all(z is not None for z in latents)
+        B, _, nH, nW = latents[0].shape
+        self._prepare(); self._set_lmb(float(lmb))
+        pl = self._plan('dec', B, nH, nW)
+        lo = 0
+        for li, cut in enumerate(pl.cuts):
+            pl.run(lo, cut)
+            lo = cut
+            zdim, hw = pl.lat_shapes[li]
+            pm = pl.pm_bufs[li].view(B, hw, zdim)
+            zt = latents[li].permute(0, 2, 3, 1).reshape(B, hw, zdim)
+            sym = torch.round(zt - pm).to(torch.int32).permute(0, 2, 1).reshape(-1)      # NCHW raster order
+            o = pl.sym_off[li]
+            pl.sym_all[o:o + sym.numel()].copy_(sym)
+        pl.run(lo, None)
+        return pl.out.clone()
+
+    @torch.no_grad()
+    def _self_evaluate(self, img_paths, lmb: float):
+        """qarv/model.py:427-473 (per-image loop; estimated bpp from the likelihoods, PSNR on the cropped reconstruction)."""
+        from PIL import Image
+        tot = {'loss': 0.0, 'bpp': 0.0, 'psnr': 0.0}
+        for impath in img_paths:
+            img = Image.open(impath)
+            h, w = img.height, img.width
+            im = coding.pil_to_tensor01(coding.pad_divisible_by(img, div=self.max_stride)).unsqueeze_(0).to(self._dummy.device)
+            im_hat, nats = self.estimate(im, lmb)
+            kl = float(nats.sum()) / (3 * h * w)                                   # nats per (original) dimension
+            real = coding.pil_to_tensor01(img).to(im_hat.device)
+            fake = im_hat[0, :, :h, :w]
+            mse = float((real - fake).square().mean())
+            distortion = 4.0 * mse      # mse between (x_hat, x_target) in (-1,1) units; uses the CLAMPED reconstruction
+            tot['loss'] += kl + lmb * distortion
+            tot['bpp'] += kl * self.log2_e * 3
+            tot['psnr'] += -10 * math.log10(mse)
+        n = len(img_paths)
+        out = {k: v / n for k, v in tot.items()}
+        out['lambda'] = lmb
+        return out
+
+    @torch.no_grad()
+    def self_evaluate(self, img_dir, lmb_range=None, steps=8, log_dir=None):
+        """qarv/model.py:491-507: estimated-rate RD sweep over `steps` lambdas log-spaced in lmb_range."""
+        from collections import defaultdict
+        from pathlib import Path
+        img_paths = sorted(Path(img_dir).rglob('*.*'))
+        start, end = self.lmb_range if (lmb_range is None) else lmb_range
+        lambdas = torch.linspace(math.log(start), math.log(end), steps=steps).exp().tolist()
+        stats = defaultdict(list)
+        for lmb in lambdas:
+            for k, v in self._self_evaluate(img_paths, lmb).items():
+                stats[k].append(v)
+        return stats
 
     # ---- debugging / test access (not on the hot path)
     @torch.no_grad()

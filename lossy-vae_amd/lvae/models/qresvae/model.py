@@ -371,7 +371,7 @@ class HierarchicalVAE(CodecBase):
         assert H % self.max_stride == 0 and W % self.max_stride == 0, f'{im.shape=}'
         self._prepare()
         tables = self._dg().host_tables()
-        groups = self._groups(B)
+        groups = self._groups(B, 'enc')
         nthreads = self._coder_threads_per_group(len(groups))
         width = self.decoder.dec_blocks[0].width
 
@@ -411,7 +411,7 @@ class HierarchicalVAE(CodecBase):
         H, W = nH * 64, nW * 64
         self._prepare()
         tables = self._dg().host_tables()
-        groups = self._groups(B)
+        groups = self._groups(B, 'dec')
         nthreads = self._coder_threads_per_group(len(groups))
         out = torch.empty(B, 3, H, W, device=self._dummy.device)
 
