@@ -147,6 +147,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     constexpr int BK = C::BK, LDT = C::LDT;
     float* Ws = smem + C::NBUF * C::BM * LDT;  // [NBUF][BN][LDT]
 
+#ifdef LVAE_GEMM_TRACE
+    const long t_entry = clock64();
+#endif
     // XCD-aware bijective remap (block b runs on XCD b%8): each XCD gets a contiguous chunk of the tile list
     int t;
     {
@@ -186,20 +189,26 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     unsigned okmask = 0;      // bit i: ra[i] is real data; bit 16: the W chunk is real data (k < K)
-    auto gload = [&](int kt) {
+    // operand loads of k-tile kt, slice `part` of `nparts` (nparts = 1: everything).  In the main loop the loads are
+    // issued in BK/8 slices, one behind each 8-deep MFMA substep: all 8 waves of a CU issuing their whole tile at once
+    // right after the barrier saturated the CU's vector-memory issue (in-kernel timeline: 2-5k cycles with NO wave in
+    // its MFMA phase, 15-25% of a k-tile); spread out, each load issues in the shadow of the preceding MFMAs.
+    auto gload = [&](int kt, int part, int nparts) {
         const int k = kt * BK + sk4 * 4;
-        okmask = 0;
+        if (part == 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < C::NA; ++i) {
+            if (i % nparts != part) continue;
             bool ok;
             ra[i] = load_a<AMODE>(d, ri[i], k, ok);
             okmask |= (ok ? 1u : 0u) << i;
         }
         const bool wok = k < d.K;
         const int kc = wok ? k : d.K - 4;
-        okmask |= (wok ? 1u : 0u) << 16;
+        if (part == 0) okmask |= (wok ? 1u : 0u) << 16;
 #pragma unroll
-        for (int i = 0; i < C::NB; ++i) rb[i] = *(const f32x4*)(wrow[i] + kc);
+        for (int i = 0; i < C::NB; ++i)
+            if ((i + C::NA) % nparts == part) rb[i] = *(const f32x4*)(wrow[i] + kc);
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * C::BM * LDT + srow * LDT + sk4 * 4;
@@ -216,20 +225,22 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
                 *(f32x4*)(w + C::RP * i * LDT) = ((okmask >> 16) & 1u) ? rb[i] : zero4;
     };
 
-    gload(0);
+    gload(0, 0, 1);
     lstore(0);
     __syncthreads();
 
 #ifdef LVAE_GEMM_TRACE
     const bool tracing = (blockIdx.x == gridDim.x / 2 + 3) && tid == 0;
+    const long t_prologue = clock64();
 #endif
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = (C::NBUF == 2) ? (kt & 1) : 0;
         TRACE_STAMP(0);
-#if defined(LVAE_GEMM_LOADSAME)
-        if (kt + 1 < nk) gload(kt & 1);
-#elif !defined(LVAE_GEMM_NOLOAD)
-        if (kt + 1 < nk) gload(kt + 1);
+        const bool more = kt + 1 < nk;
+        // small wave tiles (<= 2 MFMA blocks, 1-2k cycles of MFMA per k-tile) are latency-bound: issue their loads first
+        constexpr bool kSpreadLoads = C::TM * C::TN >= 4;
+#ifndef LVAE_GEMM_NOLOAD
+        if (!kSpreadLoads && more) gload(kt + 1, 0, 1);
 #endif
         TRACE_STAMP(1);
         const float* a_base = As + cur * C::BM * LDT + (wave_m * C::TM * 32 + li) * LDT + 4 * lh;
@@ -248,6 +259,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
 #pragma unroll
                     for (int b = 0; b < C::TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+#ifndef LVAE_GEMM_NOLOAD
+            if (kSpreadLoads) {
+                __builtin_amdgcn_sched_barrier(0);      // keep this slice of loads BEHIND the substep's MFMAs
+                if (more) gload(kt + 1, s, BK / 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
         TRACE_STAMP(2);
         if (C::NBUF == 2) {
@@ -264,7 +282,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     }
 
 #ifdef LVAE_GEMM_TRACE
-    if (tracing) for (int i = 0; i < 128; ++i) lvae_trace_buf[i] = ((long*)(smem + C::NBUF * (C::BM + C::BN) * C::LDT))[i];
+    const long t_loop = clock64();
+    if (tracing) for (int i = 0; i < 120; ++i) lvae_trace_buf[i] = ((long*)(smem + C::NBUF * (C::BM + C::BN) * C::LDT))[i];
+#define TRACE_END() do { if (tracing) { __builtin_amdgcn_s_waitcnt(0); lvae_trace_buf[120] = t_entry; lvae_trace_buf[121] = t_prologue; \
+                                         lvae_trace_buf[122] = t_loop; lvae_trace_buf[123] = clock64(); } } while (0)
+#else
+#define TRACE_END() do {} while (0)
 #endif
     // ---------------------------------------------------------------- epilogue
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -330,6 +353,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
                 }
             }
         }
+        TRACE_END();
         return;
     }
     // scalar path (final image layer, odd leading dimensions): rows-outer / columns-inner, 4-B accesses
@@ -381,6 +405,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
             }
         }
     }
+    TRACE_END();
 }
 
 template <class C, int AMODE>
@@ -455,6 +480,8 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     consider(4, 256, 192, 1, 0.88);
     consider(5, 256, 224, 1, 0.85);
     consider(6, 256, 128, 1, 0.85);
+    consider(8, 128, 192, 2, 0.92);     // measured: never slower than 256x192, 20% faster at (N=384, K=768)
+    consider(7, 128, 256, 2, 0.84);
     if (g_force_cfg >= 0) id = g_force_cfg;
     if (d->cfg > 0) id = d->cfg - 1;
     switch (id) {

@@ -16,11 +16,12 @@ int main(int argc, char** argv) {
     hipMemset(b, 0, N * 4);
     lvae_gemm_desc d = {};
     d.A0 = A; d.lda0 = K; d.K0 = K; d.Wt = W; d.ldw = K; d.bias = b; d.out = o; d.ldo = N; d.M = M; d.N = N; d.K = K;
+    d.epi = argc > 4 ? atoi(argv[4]) : 0; d.cfg = argc > 5 ? atoi(argv[5]) : 0; d.gamma = b; d.res = o; d.ldres = N;
     {
         int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_kernel<CfgA, 0>, 256, CfgA::LDS_BYTES);
-        hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)gemm_kernel<CfgA, 0>);
-        printf("occupancy API: %d blocks/CU (err %d), regs %d, static smem %zu, dyn LDS %d, maxDyn %d\n", nb, (int)e, fa.numRegs, fa.sharedSizeBytes, CfgA::LDS_BYTES, fa.maxDynamicSharedSizeBytes);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_kernel<CfgL192, 0>, 256, CfgL192::LDS_BYTES);
+        hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)gemm_kernel<CfgL192, 0>);
+        printf("occupancy API: %d blocks/CU (err %d), regs %d, static smem %zu, dyn LDS %d, maxDyn %d\n", nb, (int)e, fa.numRegs, fa.sharedSizeBytes, CfgL192::LDS_BYTES, fa.maxDynamicSharedSizeBytes);
     }
     for (int i = 0; i < 3; ++i) lvae_gemm_f32(&d, 0);
     hipDeviceSynchronize();
@@ -33,5 +34,6 @@ int main(int argc, char** argv) {
     for (int kt = 0; kt < 16 && kt < K / 32 - 1; ++kt)
         printf("%2d : %6ld %8ld %8ld %8ld | %8ld\n", kt, t[kt*8+1]-t[kt*8+0], t[kt*8+2]-t[kt*8+1], t[kt*8+3]-t[kt*8+2],
                t[kt*8+4]-t[kt*8+3], t[(kt+1)*8+0]-t[kt*8+0]);
+    printf("tile lifetime (ticks): prologue %ld, main loop %ld, epilogue %ld, total %ld\n", t[121] - t[120], t[122] - t[121], t[123] - t[122], t[123] - t[120]);
     return 0;
 }
