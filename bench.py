@@ -225,7 +225,7 @@ def main():
     if rank == 0:
         px = world * B * H * W * args.steps
         line = {
-            'metric': 'Mpixels/s enc+dec (qarv_base, 512x768)', 'value': round(px / dt / 1e6, 3), 'unit': 'Mpixels/s',
+            'metric': f'Mpixels/s enc+dec (qarv_base, {H}x{W})', 'value': round(px / dt / 1e6, 3), 'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
