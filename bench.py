@@ -59,17 +59,16 @@ class KernelTimer:
         self.pairs = []
 
     def wrap(self, plan, pred):
-        """Return a run(lo,hi) replacement for `plan` that brackets ops selected by pred(label) with events."""
+        """Return a run(lo,hi) replacement for `plan` that brackets ops selected by pred(fn, args, label) with events."""
         timer = self
         ops = plan.ops
-        flops = getattr(plan, 'op_flops', None)
 
         def run(lo=0, hi=None, stream=None):
             import ctypes
             s = torch.cuda.current_stream(plan.device)
             sp = ctypes.c_void_p(s.cuda_stream)
             for i, (fn, args, label) in enumerate(ops[lo:hi]):
-                sel = pred(label)
+                sel = pred(fn, args, label)
                 if sel:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record(s)
                 rc = fn(*args, sp)
@@ -148,7 +147,15 @@ def main():
         strings, out, _ = step()
 
     timer = KernelTimer()
-    dominant = lambda label: label.endswith('.fc1') or label.endswith('.fc2')      # noqa: E731
+    import ctypes as _ct
+    from lvae import _native as _nat
+
+    def dominant(fn, a, label):
+        """The dominant kernel = every launch of gemm_kernel<*, PLAIN> (the dense channel-mixing GEMMs: MLP fc1/fc2, i.e. 87%
+        of the path's FLOPs, plus post_merge / prior / z_proj / upsample 1x1 convs) -- one rocprofv3 kernel-name family."""
+        if fn is not _nat.lib().lvae_gemm_f32:
+            return False
+        return _ct.cast(a[0], _ct.POINTER(_nat.GemmDesc)).contents.a_mode == _nat.A_PLAIN
 
     def barrier():
         if dist is not None:
@@ -205,19 +212,19 @@ def main():
             if key[1] != B:                              # only the single-group (full batch) plans were timed
                 continue
             for fn, a, label in pl.ops:
-                if label.endswith('.fc1') or label.endswith('.fc2'):
+                if dominant(fn, a, label):
                     d = ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
                     per_step += 2 * d.M * d.N * d.K
                     alg_bytes += 4 * (d.M * d.K + d.N * d.K + d.M * d.N * (2 if d.epi in (2, 3) else 1))
         flops = per_step * args.roofline_steps
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<*,PLAIN> (ConvNeXt MLP fc1/fc2, fp32 v_mfma_f32_32x32x2_f32)',
+        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<Cfg<*>, 0> (all PLAIN fp32-MFMA GEMM launches: MLP fc1/fc2 + 1x1 convs; v_mfma_f32_32x32x2_f32)',
                 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
                 'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
                 'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
-                'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every fc1/fc2 launch',
+                'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every such launch',
                 'traffic_note': 'HBM bytes are collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE): profiles/'}
 
     if rank == 0 and model.timing is not None:
