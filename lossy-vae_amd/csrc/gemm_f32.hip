@@ -239,6 +239,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
         const bool more = kt + 1 < nk;
         // small wave tiles (<= 2 MFMA blocks, 1-2k cycles of MFMA per k-tile) are latency-bound: issue their loads first
         constexpr bool kSpreadLoads = C::TM * C::TN >= 4;
+        // all slices go out in the FIRST half of the substeps so that the remaining MFMAs still cover their latency
+        constexpr int kLoadSlices = (BK / 8 >= 4) ? BK / 16 : 1;
 #ifndef LVAE_GEMM_NOLOAD
         if (!kSpreadLoads && more) gload(kt + 1, 0, 1);
 #endif
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
 #ifndef LVAE_GEMM_NOLOAD
             if (kSpreadLoads) {
                 __builtin_amdgcn_sched_barrier(0);      // keep this slice of loads BEHIND the substep's MFMAs
-                if (more) gload(kt + 1, s, BK / 8);
+                if (more && s < kLoadSlices) gload(kt + 1, s, kLoadSlices);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -292,6 +294,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     // ---------------------------------------------------------------- epilogue
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // acc[][] is only ever indexed statically (a runtime index sends the whole accumulator tile to scratch).
+#ifdef LVAE_EPI_PRIO
+    __builtin_amdgcn_s_setprio(LVAE_EPI_PRIO);      // experiment: favour the epilogue's VALU/VMEM issue over a co-resident MFMA wave
+#endif
     const int rr = d.r, r2 = rr * rr;
     const int epi = d.epi, store = d.store;
     const int cp = (store == LVAE_ST_ROWMAJOR) ? 1 : d.N / r2;

@@ -1,5 +1,6 @@
 // In-kernel timeline of the GEMM main loop (one wave of a mid-grid block): s_memtime stamps per k-tile.
 #define LVAE_GEMM_TRACE 1
+#define LVAE_EPI_PRIO 3
 extern "C" { __device__ long* lvae_trace_buf; }
 #include "../../lossy-vae_amd/csrc/gemm_f32.hip"
 #include <stdio.h>
