@@ -344,7 +344,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
                 for (int b = 0; b < C::TN; ++b) {
                     float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
                     float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
-                    if (epi == LVAE_EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                    if (epi == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
                     else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
                     quad_transpose(v0, v1, v2, v3, lj);
                     if (rok && cok4[b]) {
