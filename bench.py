@@ -133,6 +133,8 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     model, sd = build_model(dev)
+    # one rank per GPU shares the node's host cores: give each rank its slice for the rANS coder threads
+    model.coder_threads = max(8, (os.cpu_count() or 64) // max(1, world))
     ims = synth_batch(B, H, W, rank).to(dev)
 
     def step():

@@ -197,3 +197,57 @@ def test_self_evaluate_runs(product_model, tmp_path):
     real = imcoding_evaluate(product_model, str(tmp_path))
     product_model.default_lmb = product_model.lmb_range[1]
     assert abs(stats['psnr'][1] - real['psnr']) < 1e-3
+
+
+def test_full_size_batch_properties(product_model):
+    """BASELINE.json configs[1] at full size (batch 8, 512x768), through size-independent properties: (1) the coder is
+    lossless on the quantised latents -- decompress(compress(x)) equals the coder-free path estimate(x) that feeds the
+    encoder's symbols straight into the decoder; (2) batch == single for a sampled image; (3) determinism."""
+    m = product_model
+    ims = torch.cat([_img(512, 768, 300 + i) for i in range(8)], 0).cuda()
+    strings = m.compress_batch(ims, 700.0)
+    assert len(strings) == 8 and all(struct.unpack('3H', s[4:10]) == (1, 8, 12) for s in strings)
+    xb = m.decompress_batch(strings)
+    xe, nats = m.estimate(ims, 700.0)
+    assert torch.equal(xb, xe)
+    assert nats.shape == (9, 8) and bool((nats > 0).all())
+    assert strings[5] == m.compress(ims[5:6], 700.0)
+    assert strings == m.compress_batch(ims, 700.0)
+    bits = np.array([len(s) * 8 for s in strings], dtype=np.float64)
+    est = (nats.sum(0) / math.log(2)).cpu().numpy()
+    # with the 'wide' random weights ~11% of the symbols are out-of-table: the estimate charges them the 1e-9 clamp (29.9 bits)
+    # while the coder's bypass escape is cheaper, so coded <= estimate; the tight size-vs-entropy pin is tests/test_oracle_rans.py
+    assert np.all(bits < 1.02 * est) and np.all(bits > 0.7 * est), (bits, est)
+
+
+def test_corrupt_and_mismatched_streams_raise(product_model):
+    m = product_model
+    im = _img(64, 64, 1).cuda()
+    s = m.compress(im)
+    with pytest.raises((ValueError, AssertionError)):
+        m.decompress(s[:-40])                                         # truncated payload: container length check
+    bad = bytearray(s)
+    head = 10 + 1 + 4 * 9
+    bad[head:head + 8] = b'\xff' * 8                                  # garbage rANS state in the first stream
+    try:
+        out = m.decompress(bytes(bad))
+        assert out.shape == (1, 3, 64, 64)                            # a decodable-but-wrong stream must not crash
+    except ValueError:
+        pass
+    with pytest.raises(AssertionError):
+        m.decompress_batch([s, m.compress(_img(128, 64, 1).cuda())])  # mixed shapes in one batch
+
+
+def test_max_size_image(product_model):
+    """CLIC-2022-sized input (2048x1365 padded to 2048x1408): plans, 32-bit index ranges, coder buffers."""
+    m = product_model
+    u8 = seeded_init.synthetic_image_u8(1365, 2048, 77)
+    from lvae.utils.coding import pad_divisible_by, pil_to_tensor01
+    from PIL import Image
+    im = pil_to_tensor01(pad_divisible_by(Image.fromarray(u8), 64)).unsqueeze(0).cuda()
+    assert im.shape == (1, 3, 1408, 2048)
+    s = m.compress(im, 128.0)
+    x = m.decompress(s)
+    assert x.shape == im.shape and bool(torch.isfinite(x).all())
+    xe, _ = m.estimate(im, 128.0)
+    assert torch.equal(x, xe)
