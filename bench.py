@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PROFILE = os.environ.get('LVAE_BENCH_PROFILE', 'typical')   # seeded-weight profile (lossy-vae_amd/seeded_init.py)
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
@@ -116,6 +117,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'],
+                    help="GEMM operand precision: fp32 = the parity path (headline); bf16 = BASELINE config 5 style reduced precision")
     ap.add_argument('--cpu-threads', type=int, default=16)
     args = ap.parse_args()
 
@@ -135,6 +138,7 @@ def main():
     model, sd = build_model(dev)
     # one rank per GPU shares the node's host cores: give each rank its slice for the rANS coder threads
     model.coder_threads = max(8, (os.cpu_count() or 64) // max(1, world))
+    model.set_gemm_precision(args.precision)
     ims = synth_batch(B, H, W, rank).to(dev)
 
     def step():
@@ -220,6 +224,12 @@ def main():
                     alg_bytes += 4 * (d.M * d.K + d.N * d.K + d.M * d.N * (2 if d.epi in (2, 3) else 1))
         flops = per_step * args.roofline_steps
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof_hbm = {'bound': 'hbm', 'kernel': 'gemm_bf16_kernel<Cfg<*>, 0> (all PLAIN bf16-MFMA GEMM launches; bound by the fp32 operand/result streams)',
+                    'achieved': round(alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0, 'peak': 8000.0,
+                    'unit': 'GB/s', 'frac': round(alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms > 0 else 0.0,
+                    'traffic': None, 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
+                    'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
+                    'tflops_equiv': round(ach, 2)}
         roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<Cfg<*>, 0> (all PLAIN fp32-MFMA GEMM launches: MLP fc1/fc2 + 1x1 convs; v_mfma_f32_32x32x2_f32)',
                 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
@@ -229,6 +239,8 @@ def main():
                 'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every such launch',
                 'traffic_note': 'HBM bytes are collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE): profiles/'}
 
+    if roof is not None and args.precision == 'bf16':
+        roof = roof_hbm
     if rank == 0 and model.timing is not None:
         print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)
     if rank == 0:
@@ -236,7 +248,8 @@ def main():
         line = {
             'metric': f'Mpixels/s enc+dec (qarv_base, {H}x{W})', 'value': round(px / dt / 1e6, 3), 'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'bf16-mfma (f32 activations/accumulate; NOT the parity path)', 'data': 'synthetic',
             'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
                                    f'fp32 HIP kernels + host rANS, seeded random-init weights (profile {PROFILE})', 'global_batch': world * B,
                        'parallelism': f'dp{world} (images sharded, no data-path collective)',

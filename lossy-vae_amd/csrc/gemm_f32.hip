@@ -140,6 +140,129 @@ __device__ __forceinline__ f32x4 load_a(const lvae_gemm_desc& d, const RowInfo& 
     }
 }
 
+// ---------------------------------------------------------------- epilogue (shared by the f32 and bf16 main loops)
+template <class C>
+__device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&acc)[C::TM][C::TN], int m0, int n0, int wave_m,
+                                              int wave_n, int li, int lh) {
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // acc[][] is only ever indexed statically (a runtime index sends the whole accumulator tile to scratch).
+#ifdef LVAE_EPI_PRIO
+    __builtin_amdgcn_s_setprio(LVAE_EPI_PRIO);      // experiment: favour the epilogue's VALU/VMEM issue over a co-resident MFMA wave
+#endif
+    const int rr = d.r, r2 = rr * rr;
+    const int epi = d.epi, store = d.store;
+    const int cp = (store == LVAE_ST_ROWMAJOR) ? 1 : d.N / r2;
+    const bool vec = (store == LVAE_ST_ROWMAJOR && !(d.N & 3) && !(d.ldo & 3) && !(d.ldres & 3)) ||
+                     (store == LVAE_ST_SHUFFLE && !(cp & 3));
+    if (vec) {
+        // vector path: per-column ops on the lane's own column, quad transpose, then one 16-B access per 4 outputs
+        const int lj = li & 3;
+        float cbias[C::TN], cgam[C::TN];
+        long ccol4[C::TN];
+        bool cok4[C::TN];
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b) {
+            const int colb = n0 + (wave_n * C::TN + b) * 32;
+            const int col = colb + li;
+            const int cc = col < d.N ? col : 0;
+            cbias[b] = d.bias ? d.bias[cc] : 0.f;
+            cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
+            const int c4 = colb + (li & ~3);                 // first of the 4 columns this lane stores
+            cok4[b] = c4 < d.N;
+            const int c4c = cok4[b] ? c4 : 0;
+            if (store == LVAE_ST_ROWMAJOR) {
+                ccol4[b] = c4c;
+            } else {
+                const int q = c4c / cp, sc = c4c - q * cp, si = q / rr, sj = q - si * rr;
+                ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < C::TM; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;     // row this lane stores
+                const bool rok = row < d.M;
+                const int rowc = rok ? row : 0;
+                long obase;
+                if (store == LVAE_ST_ROWMAJOR) {
+                    obase = (long)rowc * d.ldo;
+                } else {
+                    const int w = rowc % d.W, bh = rowc / d.W, h = bh % d.H, bb = bh / d.H;
+                    obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
+                }
+                const float* resrow = d.res + (long)rowc * d.ldres;
+#pragma unroll
+                for (int b = 0; b < C::TN; ++b) {
+                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
+                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
+                    if (epi == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+                    else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    if (rok && cok4[b]) {
+                        f32x4 o = {v0, v1, v2, v3};
+                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
+                            const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
+                            o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
+                        }
+                        *(f32x4*)(d.out + obase + ccol4[b]) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // scalar path (final image layer, odd leading dimensions): rows-outer / columns-inner, 4-B accesses
+    float cbias[C::TN], cgam[C::TN];
+    long ccol[C::TN];                 // ROWMAJOR: col; SHUFFLE/IMAGE: column part of the output offset
+    bool cok[C::TN];
+#pragma unroll
+    for (int b = 0; b < C::TN; ++b) {
+        const int col = n0 + (wave_n * C::TN + b) * 32 + li;
+        cok[b] = col < d.N;
+        const int cc = cok[b] ? col : 0;
+        cbias[b] = d.bias ? d.bias[cc] : 0.f;
+        cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
+        if (store == LVAE_ST_ROWMAJOR) {
+            ccol[b] = cc;
+        } else if (store == LVAE_ST_SHUFFLE) {        // column n' = (i*r+j)*cp + c
+            const int q = cc / cp, sc = cc - q * cp, si = q / rr, sj = q - si * rr;
+            ccol[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
+        } else {                                      // IMAGE: column n = c*r^2 + i*r + j -> NCHW
+            const int sc = cc / r2, q = cc - sc * r2, si = q / rr, sj = q - si * rr;
+            ccol[b] = ((long)sc * (d.H * rr) + si) * (d.W * rr) + sj;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a) {
+        const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row >= d.M) continue;
+            long obase;
+            if (store == LVAE_ST_ROWMAJOR) {
+                obase = (long)row * d.ldo;
+            } else {
+                const int w = row % d.W, bh = row / d.W, h = bh % d.H, bb = bh / d.H;
+                if (store == LVAE_ST_SHUFFLE) obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
+                else obase = ((long)bb * cp * (d.H * rr) + (long)h * rr) * (d.W * rr) + (long)w * rr;
+            }
+            const float* resrow = d.res + (long)row * d.ldres;
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) {
+                if (!cok[b]) continue;
+                float v = acc[a][b][r] + cbias[b];
+                if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
+                else if (epi == LVAE_EPI_GAMMA_RES) v = resrow[ccol[b]] + cgam[b] * v;
+                else if (epi == LVAE_EPI_RES) v = resrow[ccol[b]] + v;
+                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                d.out[obase + ccol[b]] = v;
+            }
+        }
+    }
+}
+
 template <class C, int AMODE>
 __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -291,126 +414,135 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
 #else
 #define TRACE_END() do {} while (0)
 #endif
-    // ---------------------------------------------------------------- epilogue
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // acc[][] is only ever indexed statically (a runtime index sends the whole accumulator tile to scratch).
-#ifdef LVAE_EPI_PRIO
-    __builtin_amdgcn_s_setprio(LVAE_EPI_PRIO);      // experiment: favour the epilogue's VALU/VMEM issue over a co-resident MFMA wave
-#endif
-    const int rr = d.r, r2 = rr * rr;
-    const int epi = d.epi, store = d.store;
-    const int cp = (store == LVAE_ST_ROWMAJOR) ? 1 : d.N / r2;
-    const bool vec = (store == LVAE_ST_ROWMAJOR && !(d.N & 3) && !(d.ldo & 3) && !(d.ldres & 3)) ||
-                     (store == LVAE_ST_SHUFFLE && !(cp & 3));
-    if (vec) {
-        // vector path: per-column ops on the lane's own column, quad transpose, then one 16-B access per 4 outputs
-        const int lj = li & 3;
-        float cbias[C::TN], cgam[C::TN];
-        long ccol4[C::TN];
-        bool cok4[C::TN];
-#pragma unroll
-        for (int b = 0; b < C::TN; ++b) {
-            const int colb = n0 + (wave_n * C::TN + b) * 32;
-            const int col = colb + li;
-            const int cc = col < d.N ? col : 0;
-            cbias[b] = d.bias ? d.bias[cc] : 0.f;
-            cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
-            const int c4 = colb + (li & ~3);                 // first of the 4 columns this lane stores
-            cok4[b] = c4 < d.N;
-            const int c4c = cok4[b] ? c4 : 0;
-            if (store == LVAE_ST_ROWMAJOR) {
-                ccol4[b] = c4c;
-            } else {
-                const int q = c4c / cp, sc = c4c - q * cp, si = q / rr, sj = q - si * rr;
-                ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < C::TM; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;     // row this lane stores
-                const bool rok = row < d.M;
-                const int rowc = rok ? row : 0;
-                long obase;
-                if (store == LVAE_ST_ROWMAJOR) {
-                    obase = (long)rowc * d.ldo;
-                } else {
-                    const int w = rowc % d.W, bh = rowc / d.W, h = bh % d.H, bb = bh / d.H;
-                    obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
-                }
-                const float* resrow = d.res + (long)rowc * d.ldres;
-#pragma unroll
-                for (int b = 0; b < C::TN; ++b) {
-                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
-                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
-                    if (epi == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
-                    else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
-                    quad_transpose(v0, v1, v2, v3, lj);
-                    if (rok && cok4[b]) {
-                        f32x4 o = {v0, v1, v2, v3};
-                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
-                            const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
-                            o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
-                        }
-                        *(f32x4*)(d.out + obase + ccol4[b]) = o;
-                    }
-                }
-            }
-        }
-        TRACE_END();
-        return;
-    }
-    // scalar path (final image layer, odd leading dimensions): rows-outer / columns-inner, 4-B accesses
-    float cbias[C::TN], cgam[C::TN];
-    long ccol[C::TN];                 // ROWMAJOR: col; SHUFFLE/IMAGE: column part of the output offset
-    bool cok[C::TN];
-#pragma unroll
-    for (int b = 0; b < C::TN; ++b) {
-        const int col = n0 + (wave_n * C::TN + b) * 32 + li;
-        cok[b] = col < d.N;
-        const int cc = cok[b] ? col : 0;
-        cbias[b] = d.bias ? d.bias[cc] : 0.f;
-        cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
-        if (store == LVAE_ST_ROWMAJOR) {
-            ccol[b] = cc;
-        } else if (store == LVAE_ST_SHUFFLE) {        // column n' = (i*r+j)*cp + c
-            const int q = cc / cp, sc = cc - q * cp, si = q / rr, sj = q - si * rr;
-            ccol[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
-        } else {                                      // IMAGE: column n = c*r^2 + i*r + j -> NCHW
-            const int sc = cc / r2, q = cc - sc * r2, si = q / rr, sj = q - si * rr;
-            ccol[b] = ((long)sc * (d.H * rr) + si) * (d.W * rr) + sj;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < C::TM; ++a) {
-        const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            if (row >= d.M) continue;
-            long obase;
-            if (store == LVAE_ST_ROWMAJOR) {
-                obase = (long)row * d.ldo;
-            } else {
-                const int w = row % d.W, bh = row / d.W, h = bh % d.H, bb = bh / d.H;
-                if (store == LVAE_ST_SHUFFLE) obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
-                else obase = ((long)bb * cp * (d.H * rr) + (long)h * rr) * (d.W * rr) + (long)w * rr;
-            }
-            const float* resrow = d.res + (long)row * d.ldres;
-#pragma unroll
-            for (int b = 0; b < C::TN; ++b) {
-                if (!cok[b]) continue;
-                float v = acc[a][b][r] + cbias[b];
-                if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
-                else if (epi == LVAE_EPI_GAMMA_RES) v = resrow[ccol[b]] + cgam[b] * v;
-                else if (epi == LVAE_EPI_RES) v = resrow[ccol[b]] + v;
-                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
-                d.out[obase + ccol[b]] = v;
-            }
-        }
-    }
+    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
     TRACE_END();
+}
+
+// ---------------------------------------------------------------- reduced-precision variant (BASELINE config 5)
+// Same tiles, loaders and epilogues, but the operands are rounded to bf16 (RNE) on their way into LDS and multiplied on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate): a k-tile is 64 deep (one 144-B LDS row = 64 bf16 + 8 pad, same 36-dword
+// pitch and conflict-free ds_read_b128 as the f32 tiles).  Activations stay fp32 in HBM; weights are pre-converted
+// (`Wt16`).  MFMA time drops 16x, so this kernel is bound by the operand/result streams.  NOT the parity path: results
+// differ from the reference at the 2^-9 relative level (tolerance-checked in tests/test_gpu_bf16.py); encoder and decoder
+// stay consistent because both run the same kernels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <class C, int AMODE>
+__global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KT = 64, LDT = C::LDT;          // k elements per tile; LDS row pitch in dwords (36)
+    static_assert(C::BK == 32, "bf16 tiles reuse the 36-dword row pitch");
+    char* As = (char*)smem;                                   // [NBUF][BM][144 B]
+    char* Ws = (char*)(smem + C::NBUF * C::BM * LDT);         // [NBUF][BN][144 B]
+    int t;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, r = n_tiles % 8, xcd = b % 8, loc = b / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * C::BM, n0 = tn * C::BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / C::WGN, wave_n = wave % C::WGN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // A staging: 16 float4 chunks per row; W staging: 8 chunks of 8 bf16 per row
+    constexpr int RPA = C::NT / 16, NA = C::BM / RPA, RPW = C::NT / 8, NB = (C::BN + RPW - 1) / RPW;
+    static_assert(C::BM % RPA == 0, "A tile rows");
+    const int arow = tid >> 4, ak4 = tid & 15;
+    const int wrow_i = tid >> 3, wk8 = tid & 7;
+    RowInfo ri[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ri[i] = row_info<AMODE>(d, m0 + arow + RPA * i);
+    const unsigned short* wptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + wrow_i + RPW * i;
+        wptr[i] = d.Wt16 + (long)(n < d.N ? n : d.N - 1) * d.ldw;
+    }
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ra[NA];
+    bf16x8 rb[NB];
+    unsigned okmask = 0;
+    const int nk = (d.K + KT - 1) / KT;
+    auto gload = [&](int kt, int part, int nparts) {
+        const int k = kt * KT + ak4 * 4;
+        if (part == 0) okmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i % nparts != part) continue;
+            bool ok;
+            ra[i] = load_a<AMODE>(d, ri[i], k, ok);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+        const int kw = kt * KT + wk8 * 8;
+        const bool wok = kw < d.K;
+        const int kc = wok ? kw : d.K - 8;
+        if (part == 0) okmask |= (wok ? 1u : 0u) << 16;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if ((i + NA) % nparts == part) rb[i] = *(const bf16x8*)(wptr[i] + kc);
+    };
+    auto lstore = [&](int buf) {
+        char* a = As + ((long)buf * C::BM + arow) * (LDT * 4) + ak4 * 8;
+        char* w = Ws + ((long)buf * C::BN + wrow_i) * (LDT * 4) + wk8 * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = ((okmask >> i) & 1u) ? ra[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (d.a_gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            *(bf16x4*)(a + (long)RPA * i * (LDT * 4)) = __builtin_convertvector(v, bf16x4);     // RNE
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (C::BN % RPW == 0 || wrow_i + RPW * i < C::BN) {
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+                *(bf16x8*)(w + (long)RPW * i * (LDT * 4)) = ((okmask >> 16) & 1u) ? rb[i] : z;
+            }
+    };
+
+    gload(0, 0, 1);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = (C::NBUF == 2) ? (kt & 1) : 0;
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1, 0, 1);            // MFMA phase is short here: loads first, they dominate the tile time
+        const char* a_base = As + ((long)cur * C::BM + wave_m * C::TM * 32 + li) * (LDT * 4) + 16 * lh;
+        const char* b_base = Ws + ((long)cur * C::BN + wave_n * C::TN * 32 + li) * (LDT * 4) + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < KT / 16; ++s) {       // one MFMA k-step = 16: lane (i, h) supplies k = 16 s + 8 h .. +7
+            bf16x8 af[C::TM], bf[C::TN];
+#pragma unroll
+            for (int a = 0; a < C::TM; ++a) af[a] = *(const bf16x8*)(a_base + (long)a * 32 * (LDT * 4) + 32 * s);
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) bf[b] = *(const bf16x8*)(b_base + (long)b * 32 * (LDT * 4) + 32 * s);
+#pragma unroll
+            for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+                for (int b = 0; b < C::TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (C::NBUF == 2) {
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+        } else if (more) {
+            __syncthreads();
+            lstore(0);
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 }
 
 template <class C, int AMODE>
@@ -422,7 +554,18 @@ int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        if constexpr (C::BK == 32) {
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
+    }
+    if constexpr (C::BK == 32) {
+        if (d->prec == 1) {
+            hipLaunchKernelGGL((gemm_bf16_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
+            return (int)hipGetLastError();
+        }
     }
     hipLaunchKernelGGL((gemm_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();
@@ -489,6 +632,8 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     consider(7, 128, 256, 2, 0.84);
     if (g_force_cfg >= 0) id = g_force_cfg;
     if (d->cfg > 0) id = d->cfg - 1;
+    if (d->prec == 1 && id == 10) id = 2;
+    if (d->prec == 1 && id == 11) id = 1;
     switch (id) {
         case 0: return launch_cfg<CfgA, AMODE>(d, st);
         case 1: return launch_cfg<CfgB, AMODE>(d, st);
@@ -512,8 +657,10 @@ extern "C" int lvae_gemm_num_configs(void) { return 12; }
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     static bool env_read = false;
     if (!env_read) { const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e); env_read = true; }
-    if (!d || !d->A0 || !d->Wt || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
+    if (!d || !d->A0 || (!d->Wt && !(d->prec == 1 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
+    if (d->prec != 0 && d->prec != 1) return -22;
+    if (d->prec == 1 && (!d->Wt16 || (d->K & 7) || (d->ldw & 7))) return -22;
     if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
     if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
     if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;

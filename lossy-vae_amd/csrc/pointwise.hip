@@ -449,5 +449,5 @@ extern "C" int lvae_gelu_f32(const float* x, float* y, long n, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 4; }
+extern "C" int lvae_abi_version(void) { return 5; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -68,6 +68,7 @@ class Plan:
         self.keep = []         # tensors / descs that must outlive the plan
         self.bufs = {}
         self.flops = 0
+        self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
 
@@ -92,9 +93,11 @@ class Plan:
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, a_gelu=0, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, label='gemm'):
         if K is None:
             K = K0 + K1
+        if Wt16 is None and self.w16 is not None:
+            Wt16 = self.w16.get(Wt)
         d = GemmDesc()
         d.A0, d.A1 = A0, A1
         d.lda0, d.lda1 = (lda0 if lda0 is not None else K0), lda1
@@ -106,6 +109,8 @@ class Plan:
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
         d.cfg = 0
         d.a_gelu = a_gelu
+        d.prec = 1 if (Wt16 and K % 8 == 0) else 0      # reduced-precision mode (bf16 MFMA): only when the plan provides bf16 weights
+        d.Wt16 = Wt16 if d.prec else None
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             d.cfg = autotune_gemm(self.lib, d, sp, self.device)

@@ -6,6 +6,21 @@ import torch
 import torch.nn as nn
 
 
+import threading
+_W16_LOCK = threading.Lock()
+
+
+def bf16_weight_map(tensors):
+    """{address of fp32 GEMM weight: bf16 copy} for every 2-D packed weight (kept alive by the returned holder list)."""
+    keep, amap = [], {}
+    for name, t in tensors.items():
+        if t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 8 == 0:
+            h = t.to(torch.bfloat16).contiguous()
+            keep.append(h)
+            amap[t.data_ptr()] = h.data_ptr()
+    return amap, keep
+
+
 class CodecBase(nn.Module):
     def _init_codec_base(self):
         self.coder_threads = 0          # 0 = all hardware threads
@@ -14,6 +29,13 @@ class CodecBase(nn.Module):
         self.dec_groups = int(os.environ.get('LVAE_DEC_GROUPS', '0'))
         self._streams = []
         self._pool = None
+        self._prec = 'fp32'
+
+    def set_gemm_precision(self, mode):
+        """'fp32' (default; the parity path: exact fp32 MFMA) or 'bf16' (BASELINE config 5: GEMM operands rounded to bf16,
+        fp32 accumulate on the bf16 MFMA; activations stay fp32; not bit-compatible with fp32-mode bitstreams)."""
+        assert mode in ('fp32', 'bf16')
+        self._prec = mode
 
     def _coder_threads_per_group(self, n_groups):
         if n_groups == 1:

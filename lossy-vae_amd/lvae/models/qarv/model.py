@@ -185,6 +185,15 @@ class _Packed:
     def p(self, name):
         return self.t[name].data_ptr()
 
+    def bf16_map(self):
+        """Built once, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second builder
+        would free the first one's bf16 copies while its plan still points at them."""
+        from ..base import bf16_weight_map, _W16_LOCK
+        with _W16_LOCK:
+            if getattr(self, '_w16', None) is None:
+                self._w16, self._w16_keep = bf16_weight_map(self.t)
+        return self._w16
+
 
 class _NetPlan(Plan):
     """Shared recording helpers for the encode and decode plans."""
@@ -192,6 +201,7 @@ class _NetPlan(Plan):
     def __init__(self, model, pk, B):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
+        self.w16 = pk.bf16_map() if model._prec == 'bf16' else None
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
         self.lat_shapes = []                    # (z, HW)
@@ -478,7 +488,7 @@ class VariableRateLossyVAE(CodecBase):
         self._cur_lmb = lmb
 
     def _plan(self, kind, B, a, b, group=0):
-        key = (kind, B, a, b, group)
+        key = (kind, B, a, b, group, self._prec)
         pl = self._plans.get(key)
         if pl is None:
             pk = self._prepare()

@@ -163,11 +163,21 @@ class _Packed:
     def p(self, name):
         return self.t[name].data_ptr()
 
+    def bf16_map(self):
+        """Built once, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second builder
+        would free the first one's bf16 copies while its plan still points at them."""
+        from ..base import bf16_weight_map, _W16_LOCK
+        with _W16_LOCK:
+            if getattr(self, '_w16', None) is None:
+                self._w16, self._w16_keep = bf16_weight_map(self.t)
+        return self._w16
+
 
 class _QresPlan(Plan):
     def __init__(self, model, pk, B, H, W, encode):
         super().__init__(pk.device)
         lib, self.pk, self.B = self.lib, pk, B
+        self.w16 = pk.bf16_map() if model._prec == 'bf16' else None
         self.lat_shapes, self.idx_off, self.sym_off, self.cuts = [], [], [], []
         nH, nW = H // 64, W // 64
         # latent I/O sizes: resolution doubles at every rate-2 upsample of the top-down path
@@ -339,7 +349,7 @@ class HierarchicalVAE(CodecBase):
         return self._packed
 
     def _plan(self, kind, B, H, W, group=0):
-        key = (kind, B, H, W, group)
+        key = (kind, B, H, W, group, self._prec)
         pl = self._plans.get(key)
         if pl is None:
             pl = _QresPlan(self, self._prepare(), B, H, W, encode=(kind == 'enc'))
