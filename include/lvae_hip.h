@@ -112,9 +112,14 @@ typedef struct {
     int  a_mode, epi, store, r;           /* r = pixel-shuffle factor */
     int  a_gelu;                          /* 1: apply gelu_erf to every A element on load (VDBlock's c1(gelu(x)),
                                              lvae/models/qresvae/model.py:143-144) */
-    int  prec;                            /* 0: exact fp32 MFMA (the parity path); 1: operands rounded to bf16 (RNE), fp32
-                                             accumulate on v_mfma_f32_32x32x16_bf16; needs Wt16, K % 8 == 0 (config 5) */
-    const unsigned short* Wt16;           /* prec 1: the weights as bf16 bit patterns, [N][K] with row stride ldw */
+    int  prec;                            /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, an exact fmaf chain);
+                                             1: operands rounded to bf16 (RNE), fp32 accumulate on v_mfma_f32_32x32x16_bf16
+                                                (BASELINE config 5, not the parity path);
+                                             2: "bf16x3": each fp32 operand split exactly into hi+mid+lo bf16 terms, six
+                                                cross-term bf16 MFMAs per step, fp32 accumulate -- fp32-class accuracy
+                                                (relative error of a product <= 2^-24).  prec 1/2 need Wt16, K % 8 == 0 */
+    const unsigned short* Wt16;           /* prec 1: weights as bf16 bit patterns, [N][K], row stride ldw;
+                                             prec 2: three such planes hi | mid | lo, plane stride N*ldw elements */
     int  cfg;                             /* tile configuration: 0 = library heuristic, k>0 = candidate k-1 of
                                              lvae_gemm_num_configs() (results are bit-identical for every choice;
                                              the Python host autotunes this per shape at plan-build time) */

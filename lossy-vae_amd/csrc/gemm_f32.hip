@@ -545,6 +545,152 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_des
     gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 }
 
+// ---------------------------------------------------------------- fp32-accurate split variant ("bf16x3")
+// Every fp32 operand is split exactly into three bf16 terms  x = hi + mid + lo  (hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid); residual <= 2^-25 |x|) and the product is formed from the six largest cross terms
+//   a*b ~= hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)        (dropped terms <= 2^-24 |a*b|)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 MFMAs of 32 cycles per 16-deep step instead of 8 f32 MFMAs of
+// 64 cycles -- 2.7x less matrix-pipe time at fp32-class accuracy (bf16 x bf16 products are exact in fp32).  Activations stay
+// fp32 in HBM and are split on their way into LDS (3 planes of 64 B per 32-deep row, 208-B pitch: conflict-free
+// ds_read_b128); weights are pre-split on the host into three [N][K] bf16 planes (Wt16, plane stride N*ldw).
+// Single LDS stage (2 barriers per k-tile) so that every tile shape fits; results do not depend on the tile shape.
+template <class C, int AMODE>
+__global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KT = 32, ROWB = 208;
+    char* As = (char*)smem;                       // [BM][208 B]
+    char* Ws = As + C::BM * ROWB;                 // [BN][208 B]
+    int t;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, r = n_tiles % 8, xcd = b % 8, loc = b / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * C::BM, n0 = tn * C::BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / C::WGN, wave_n = wave % C::WGN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    constexpr int RPA = C::NT / 8, NA = C::BM / RPA, RPW = C::NT / 4, NB = (C::BN + RPW - 1) / RPW;
+    static_assert(C::BM % RPA == 0, "A tile rows");
+    const int arow = tid >> 3, ak4 = tid & 7;
+    const int wrow_i = tid >> 2, wk8 = tid & 3;
+    RowInfo ri[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ri[i] = row_info<AMODE>(d, m0 + arow + RPA * i);
+    const unsigned short* wptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + wrow_i + RPW * i;
+        wptr[i] = d.Wt16 + (long)(n < d.N ? n : d.N - 1) * d.ldw;
+    }
+    const long plane = (long)d.N * d.ldw;
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ra[NA];
+    bf16x8 rb[3][NB];
+    unsigned okmask = 0;
+    const int nk = (d.K + KT - 1) / KT;
+    auto gload = [&](int kt) {
+        const int k = kt * KT + ak4 * 4;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            bool ok;
+            ra[i] = load_a<AMODE>(d, ri[i], k, ok);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+        const int kw = kt * KT + wk8 * 8;
+        const bool wok = kw < d.K;
+        const int kc = wok ? kw : d.K - 8;
+        okmask |= (wok ? 1u : 0u) << 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[p][i] = *(const bf16x8*)(wptr[i] + p * plane + kc);
+    };
+    auto lstore = [&]() {
+        char* a = As + (long)arow * ROWB + ak4 * 8;
+        char* w = Ws + (long)wrow_i * ROWB + wk8 * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = ((okmask >> i) & 1u) ? ra[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (d.a_gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
+            const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+            const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+            const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+            char* dst = a + (long)RPA * i * ROWB;
+            *(bf16x4*)(dst) = hi;
+            *(bf16x4*)(dst + 64) = mid;
+            *(bf16x4*)(dst + 128) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (C::BN % RPW == 0 || wrow_i + RPW * i < C::BN) {
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+                const bool wok = (okmask >> 16) & 1u;
+                char* dst = w + (long)RPW * i * ROWB;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *(bf16x8*)(dst + 64 * p) = wok ? rb[p][i] : z;
+            }
+    };
+
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const char* a_base = As + (long)(wave_m * C::TM * 32 + li) * ROWB + 16 * lh;
+        const char* b_base = Ws + (long)(wave_n * C::TN * 32 + li) * ROWB + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < KT / 16; ++s) {
+            bf16x8 af[C::TM][3];
+#pragma unroll
+            for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[a][p] = *(const bf16x8*)(a_base + (long)a * 32 * ROWB + 64 * p + 32 * s);
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) {
+                bf16x8 bf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[p] = *(const bf16x8*)(b_base + (long)b * 32 * ROWB + 64 * p + 32 * s);
+                // smallest cross terms first, (hi, hi) last
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[0], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[2], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[1], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[0], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[1], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[0], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (more) {
+            __syncthreads();
+            lstore();
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+}
+
 template <class C, int AMODE>
 int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
     const int tiles_m = (d->M + C::BM - 1) / C::BM, tiles_n = (d->N + C::BN - 1) / C::BN;
@@ -558,12 +704,21 @@ int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
             e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     C::LDS_BYTES);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)gemm_x3_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (C::BM + C::BN) * 208);
+            if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
     if constexpr (C::BK == 32) {
         if (d->prec == 1) {
             hipLaunchKernelGGL((gemm_bf16_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
+            return (int)hipGetLastError();
+        }
+        if (d->prec == 2) {
+            constexpr int lds_x3 = (C::BM + C::BN) * 208;
+            static_assert(lds_x3 <= 160 * 1024, "x3 LDS");
+            hipLaunchKernelGGL((gemm_x3_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), lds_x3, st, *d, tiles_n, n_tiles);
             return (int)hipGetLastError();
         }
     }
@@ -632,8 +787,9 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     consider(7, 128, 256, 2, 0.84);
     if (g_force_cfg >= 0) id = g_force_cfg;
     if (d->cfg > 0) id = d->cfg - 1;
-    if (d->prec == 1 && id == 10) id = 2;
-    if (d->prec == 1 && id == 11) id = 1;
+    if (d->prec != 0 && id == 10) id = 2;
+    if (d->prec != 0 && id == 11) id = 1;
+    if (d->prec == 2 && id == 7) id = 3;          // 128x256 x3 instance spills; 256x256 covers the same shapes
     switch (id) {
         case 0: return launch_cfg<CfgA, AMODE>(d, st);
         case 1: return launch_cfg<CfgB, AMODE>(d, st);
@@ -657,10 +813,10 @@ extern "C" int lvae_gemm_num_configs(void) { return 12; }
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     static bool env_read = false;
     if (!env_read) { const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e); env_read = true; }
-    if (!d || !d->A0 || (!d->Wt && !(d->prec == 1 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
+    if (!d || !d->A0 || (!d->Wt && !(d->prec != 0 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
-    if (d->prec != 0 && d->prec != 1) return -22;
-    if (d->prec == 1 && (!d->Wt16 || (d->K & 7) || (d->ldw & 7))) return -22;
+    if (d->prec < 0 || d->prec > 2) return -22;
+    if (d->prec != 0 && (!d->Wt16 || (d->K & 7) || (d->ldw & 7))) return -22;
     if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
     if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
     if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;

@@ -68,6 +68,7 @@ class Plan:
         self.keep = []         # tensors / descs that must outlive the plan
         self.bufs = {}
         self.flops = 0
+        self.prec = 0          # lvae_gemm_desc.prec for this plan's GEMMs (0 fp32, 1 bf16, 2 bf16x3)
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
@@ -109,7 +110,7 @@ class Plan:
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
         d.cfg = 0
         d.a_gelu = a_gelu
-        d.prec = 1 if (Wt16 and K % 8 == 0) else 0      # reduced-precision mode (bf16 MFMA): only when the plan provides bf16 weights
+        d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0) else 0    # bf16 / bf16x3 only when the plan provides the bf16 planes
         d.Wt16 = Wt16 if d.prec else None
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

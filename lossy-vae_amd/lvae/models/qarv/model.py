@@ -185,14 +185,16 @@ class _Packed:
     def p(self, name):
         return self.t[name].data_ptr()
 
-    def bf16_map(self):
-        """Built once, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second builder
-        would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, _W16_LOCK
+    def bf16_map(self, mode):
+        """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
+        builder would free the first one's bf16 copies while its plan still points at them."""
+        from ..base import bf16_weight_map, bf16x3_weight_map, _W16_LOCK
         with _W16_LOCK:
-            if getattr(self, '_w16', None) is None:
-                self._w16, self._w16_keep = bf16_weight_map(self.t)
-        return self._w16
+            if not hasattr(self, '_w16'):
+                self._w16 = {}
+            if mode not in self._w16:
+                self._w16[mode] = (bf16_weight_map if mode == 'bf16' else bf16x3_weight_map)(self.t)
+        return self._w16[mode][0]
 
 
 class _NetPlan(Plan):
@@ -201,7 +203,8 @@ class _NetPlan(Plan):
     def __init__(self, model, pk, B):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
-        self.w16 = pk.bf16_map() if model._prec == 'bf16' else None
+        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[model._prec]
+        self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
         self.lat_shapes = []                    # (z, HW)

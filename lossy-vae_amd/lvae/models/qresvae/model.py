@@ -163,21 +163,24 @@ class _Packed:
     def p(self, name):
         return self.t[name].data_ptr()
 
-    def bf16_map(self):
-        """Built once, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second builder
-        would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, _W16_LOCK
+    def bf16_map(self, mode):
+        """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
+        builder would free the first one's bf16 copies while its plan still points at them."""
+        from ..base import bf16_weight_map, bf16x3_weight_map, _W16_LOCK
         with _W16_LOCK:
-            if getattr(self, '_w16', None) is None:
-                self._w16, self._w16_keep = bf16_weight_map(self.t)
-        return self._w16
+            if not hasattr(self, '_w16'):
+                self._w16 = {}
+            if mode not in self._w16:
+                self._w16[mode] = (bf16_weight_map if mode == 'bf16' else bf16x3_weight_map)(self.t)
+        return self._w16[mode][0]
 
 
 class _QresPlan(Plan):
     def __init__(self, model, pk, B, H, W, encode):
         super().__init__(pk.device)
         lib, self.pk, self.B = self.lib, pk, B
-        self.w16 = pk.bf16_map() if model._prec == 'bf16' else None
+        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[model._prec]
+        self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.lat_shapes, self.idx_off, self.sym_off, self.cuts = [], [], [], []
         nH, nW = H // 64, W // 64
         # latent I/O sizes: resolution doubles at every rate-2 upsample of the top-down path

@@ -61,6 +61,7 @@ def test_model_bf16_mode(product_model):
     m = product_model
     ims = torch.cat([seeded(256, 384, s) for s in (50, 51)], 0).cuda()
     lmb = 512.0
+    base_mode = m._prec
     s32 = m.compress_batch(ims, lmb)
     x32 = m.decompress_batch(s32)
     try:
@@ -71,7 +72,7 @@ def test_model_bf16_mode(product_model):
         assert torch.equal(x16, xe)                       # coder + enc/dec prior consistency in the reduced-precision mode
         assert s16 == m.compress_batch(ims, lmb)
     finally:
-        m.set_gemm_precision('fp32')
+        m.set_gemm_precision(base_mode)
     assert m.compress_batch(ims, lmb) == s32              # switching back restores the parity path bit for bit
 
     def psnr(x):
@@ -86,3 +87,39 @@ def test_model_bf16_mode(product_model):
 def seeded(h, w, seed):
     u8 = seeded_init.synthetic_image_u8(h, w, seed)
     return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(300, 192, 384, 0), (1000, 384, 192, 1), (513, 128, 8, 3), (2048, 448, 256, 2),
+                                       (129, 96, 1024, 0), (4096, 512, 2048, 0), (777, 48, 128, 0), (24576, 384, 192, 1)])
+def test_gemm_bf16x3_is_fp32_class(M, N, K, epi):
+    """prec 2: error against an fp64 reference of the UNROUNDED fp32 operands must be of the same class as the exact fp32
+    MFMA path's (<= 2x + 1e-6), on data with a wide dynamic range."""
+    from lvae import _native
+    from lvae.models.base import split_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    W3 = split_bf16x3(Wt)
+    assert float((W3.float().sum(0) - Wt).abs().max()) <= 2 ** -24 * float(Wt.abs().max())
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    ref = A.double() @ Wt.double().t() + bias.double()
+    if epi == 1:
+        ref = F.gelu(ref)
+    elif epi == 2:
+        ref = res.double() + gamma.double() * ref
+    elif epi == 3:
+        ref = res.double() + ref
+    errs = []
+    for prec in (0, 2):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = A.data_ptr(), K, K, Wt.data_ptr(), W3.data_ptr(), K
+        d.bias, d.gamma, d.res, d.ldres, d.out, d.ldo = bias.data_ptr(), gamma.data_ptr(), res.data_ptr(), N, out.data_ptr(), N
+        d.M, d.N, d.K, d.epi, d.prec = M, N, K, epi, prec
+        assert L.lvae_gemm_f32(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        errs.append(float((out.double() - ref).abs().max()))
+    print(f'M={M} N={N} K={K}: max err fp32-MFMA {errs[0]:.3e}, bf16x3 {errs[1]:.3e}')
+    assert errs[1] <= 2 * errs[0] + 1e-6

@@ -27,9 +27,19 @@ def _img(h, w, seed, kind='natural'):
     return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
 
 
+@pytest.mark.parametrize('prec', ['bf16x3', 'fp32'])
 @pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
-def test_golden_symbols_and_reconstruction(product_model, golden_dir, tag, seed):
+def test_golden_symbols_and_reconstruction(product_model, golden_dir, tag, seed, prec):
+    """Both fp32-accurate GEMM arithmetics (the default 3-term bf16 split and the exact fp32 MFMA) against the reference."""
     m = product_model
+    m.set_gemm_precision(prec)
+    try:
+        _golden_case(m, golden_dir, tag, seed)
+    finally:
+        m.set_gemm_precision('bf16x3')
+
+
+def _golden_case(m, golden_dir, tag, seed):
     g = np.load(os.path.join(golden_dir, f'qarv_base_{tag}.npz'))
     h, w = g['hw'].tolist()
     im = _img(h, w, seed).cuda()

@@ -41,6 +41,12 @@ def bench_gemm(M, N, K, epi):
     d = GemmDesc()
     d.A0, d.lda0, d.K0, d.Wt, d.ldw, d.bias, d.gamma = A.data_ptr(), K, K, Wt.data_ptr(), K, bias.data_ptr(), gamma.data_ptr()
     d.res, d.ldres, d.out, d.ldo, d.M, d.N, d.K, d.epi = res.data_ptr(), N, out.data_ptr(), N, M, N, K, epi
+    prec = int(os.environ.get('LVAE_PREC', '0'))
+    if prec:
+        from lvae.models.base import split_bf16x3
+        w16 = split_bf16x3(Wt) if prec == 2 else Wt.to(torch.bfloat16).contiguous()
+        d.Wt16, d.prec = w16.data_ptr(), prec
+        d._keep = w16
     t = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(d), st()))
     return t
 
