@@ -245,7 +245,8 @@ def main():
     if roof is not None and args.precision == 'bf16x3':
         # algorithmic fp32 FLOPs against the bf16 dense MFMA peak divided by the 6 MFMAs each product step costs
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        roof.update({'kernel': 'gemm_x3_kernel<Cfg<*>, 0> (all PLAIN GEMM launches; v_mfma_f32_32x32x16_bf16 x 6 cross terms)',
+        roof.update({'kernel': 'gemm_x3k16_kernel<TN> / gemm_x3w8_kernel / gemm_x3_kernel<Cfg<*>, 0> (all PLAIN GEMM launches; '
+                               'v_mfma_f32_32x32x16_bf16 x 6 cross terms)',
                      'peak': round(peak, 1), 'frac': round(roof['achieved'] / peak, 4),
                      'peak_note': '2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product step; vs the 157.3 TFLOP/s fp32 MFMA '
                                   f"peak this launch family runs at {roof['achieved'] / PEAK_FP32_MFMA_TFLOPS:.3f}"})

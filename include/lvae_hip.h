@@ -119,7 +119,9 @@ typedef struct {
                                                 cross-term bf16 MFMAs per step, fp32 accumulate -- fp32-class accuracy
                                                 (relative error of a product <= 2^-24).  prec 1/2 need Wt16, K % 8 == 0 */
     const unsigned short* Wt16;           /* prec 1: weights as bf16 bit patterns, [N][K], row stride ldw;
-                                             prec 2: three such planes hi | mid | lo, plane stride N*ldw elements */
+                                             prec 2: three such planes hi | mid | lo, plane stride N*ldw elements,
+                                             followed -- when K % 32 == 0 and ldw == K -- by the same values in
+                                             k16-interleaved order [N][K/16][3][16] (lvae.models.base.pack_bf16x3) */
     int  cfg;                             /* tile configuration: 0 = library heuristic, k>0 = candidate k-1 of
                                              lvae_gemm_num_configs() (results are bit-identical for every choice;
                                              the Python host autotunes this per shape at plan-build time) */

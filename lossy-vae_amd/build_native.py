@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lvae', '_native')
 OUT = os.path.join(OUT_DIR, 'liblvae_hip.so')
-SOURCES = ['gemm_f32.hip', 'pointwise.hip', 'rans_host.cpp']
+SOURCES = ['gemm_f32.hip', 'gemm_x3v2.hip', 'pointwise.hip', 'rans_host.cpp']
+HEADERS = ['gemm_common.h', 'device_math.h']
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lvae_hip.h')
 
 
@@ -19,7 +20,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER, os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [HEADER, os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -28,17 +29,23 @@ def build(force=False, verbose=True):
     if not (force or _stale()):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = []
-    for s in SOURCES:
+    objs, procs = [], []
+    hdr_t = max(os.path.getmtime(d) for d in [os.path.join(CSRC, h) for h in HEADERS] + [HEADER, os.path.abspath(__file__)])
+    for s in SOURCES:                                      # translation units compile concurrently; unchanged ones are kept
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT_DIR, s + '.o')
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
         if s.endswith('.cpp'):
             cmd.insert(1, '-x'); cmd.insert(2, 'hip')      # host-only TU still goes through hipcc for one toolchain
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + ['-lpthread']
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -5,7 +5,11 @@
 // erf(x) to < 1 ulp (max abs error 5.8e-8, checked against fp64 erf on a dense grid: tests/test_gpu_kernels.py::test_erf)
 // with 13 FMAs + one v_exp_f32, branch-free: a minimax polynomial in x^2 for |x| <= 0.9277 and 1 - exp(p(|x|)) beyond.
 // Replaces the device-library erff (about twice the VALU work) in the GELU epilogue, where it was ~15% of an fc1 launch.
+// No implicit mul+add contraction in these helpers (explicit fmaf only): the same GELU is evaluated in GEMM epilogues, GEMM
+// operand loaders and the pointwise kernel, and its bits must not depend on the surrounding code (torch's CPU kernel, the
+// reference, does not fuse x*0.5*(1+erf) either).
 __device__ __forceinline__ float lvae_erff(float a) {
+#pragma clang fp contract(off)
     const float t = fabsf(a), s = a * a;
     float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
     const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
@@ -30,6 +34,7 @@ __device__ __forceinline__ float lvae_erff(float a) {
 // do not overlap on a SIMD, so every VALU instruction in an epilogue is serial time: the polynomial halves.
 typedef float lvae_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lvae_f2 lvae_erff2(lvae_f2 a) {
+#pragma clang fp contract(off)
     const lvae_f2 t = {fabsf(a[0]), fabsf(a[1])};
     const lvae_f2 s = a * a;
     lvae_f2 r = __builtin_elementwise_fma((lvae_f2)(-1.72853470e-5f), t, (lvae_f2)(3.83197126e-4f));
@@ -51,6 +56,7 @@ __device__ __forceinline__ lvae_f2 lvae_erff2(lvae_f2 a) {
     return o;
 }
 __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
+#pragma clang fp contract(off)
     const lvae_f2 x = {x0, x1};
     const lvae_f2 e = lvae_erff2(x * (lvae_f2)(0.70710678118654752440f));
     const lvae_f2 g = ((lvae_f2)(0.5f) * x) * ((lvae_f2)(1.0f) + e);
@@ -58,4 +64,7 @@ __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
 }
 
 // exact-erf GELU (nn.GELU() default; lvae/models/common.py:124,132)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + lvae_erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+    return 0.5f * x * (1.0f + lvae_erff(x * 0.70710678118654752440f));
+}

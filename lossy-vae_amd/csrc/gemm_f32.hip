@@ -39,53 +39,9 @@ extern "C" __device__ long* lvae_trace_buf;          // [16 k-tiles][8 stamps], 
 #define TRACE_STAMP(slot) do {} while (0)
 #endif
 
+#include "gemm_common.h"
+
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-
-
-// 4x4 transpose across the 4 lanes of a quad with DPP quad_perm moves (lane^1: [1,0,3,2] = 0xB1, lane^2: [2,3,0,1] =
-// 0x4E): afterwards lane j holds in (v0..v3) what lanes 0..3 of its quad held in register j.  Used to turn the MFMA
-// accumulator layout (4 consecutive ROWS per lane) into 4 consecutive COLUMNS per lane => 16-B stores / residual loads.
-__device__ __forceinline__ float dpp_xor1(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_xor2(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int j) {
-    const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
-    float t;
-    t = dpp_xor1(o1 ? v0 : v1); if (o1) v0 = t; else v1 = t;
-    t = dpp_xor1(o1 ? v2 : v3); if (o1) v2 = t; else v3 = t;
-    t = dpp_xor2(o2 ? v0 : v2); if (o2) v0 = t; else v2 = t;
-    t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
-}
-
-template <int WGM_, int WGN_, int TM_, int TN_, int NBUF_ = 2, int BK_ = 32>
-struct Cfg {
-    static constexpr int BK = BK_;                // k-tile depth (32, or 64 for the small latency-bound problems)
-    static constexpr int LDT = BK + 4;            // padded LDS row (floats): rows*LDT mod 64 distinct multiples of 4
-    static constexpr int CPR = BK / 4;            // 16-B chunks per tile row
-    static constexpr int WGM = WGM_, WGN = WGN_, TM = TM_, TN = TN_;
-    static constexpr int NBUF = NBUF_;            // LDS stages: 2 = double-buffered (1 barrier / k-tile), 1 = single (2 barriers)
-    static constexpr int NT = 64 * WGM * WGN;     // threads per workgroup (4 or 8 wave64)
-    static constexpr int BM = WGM * TM * 32;
-    static constexpr int BN = WGN * TN * 32;
-    static constexpr int RP = NT / CPR;           // tile rows staged per pass (CPR lanes x 16 B = one row segment)
-    static constexpr int NA = (BM + RP - 1) / RP; // float4 loads per thread per k-tile (A)
-    static constexpr int NB = (BN + RP - 1) / RP; // (W)
-#ifdef LVAE_GEMM_TRACE
-    static constexpr int LDS_BYTES = NBUF * (BM + BN) * LDT * 4 + 1024;
-#else
-    static constexpr int LDS_BYTES = NBUF * (BM + BN) * LDT * 4;
-#endif
-    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
-    static_assert(BM % RP == 0, "A tile must be a whole number of staging passes");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-};
 
 struct RowInfo {      // per staged A row of this thread (rows beyond M are clamped to M-1: loaded, never stored)
     const float* p0;  // PLAIN: A0 + m*lda0;      PATCH2/CONV3: address of the row's own pixel / first tap
@@ -141,127 +97,6 @@ __device__ __forceinline__ f32x4 load_a(const lvae_gemm_desc& d, const RowInfo& 
 }
 
 // ---------------------------------------------------------------- epilogue (shared by the f32 and bf16 main loops)
-template <class C>
-__device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&acc)[C::TM][C::TN], int m0, int n0, int wave_m,
-                                              int wave_n, int li, int lh) {
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // acc[][] is only ever indexed statically (a runtime index sends the whole accumulator tile to scratch).
-#ifdef LVAE_EPI_PRIO
-    __builtin_amdgcn_s_setprio(LVAE_EPI_PRIO);      // experiment: favour the epilogue's VALU/VMEM issue over a co-resident MFMA wave
-#endif
-    const int rr = d.r, r2 = rr * rr;
-    const int epi = d.epi, store = d.store;
-    const int cp = (store == LVAE_ST_ROWMAJOR) ? 1 : d.N / r2;
-    const bool vec = (store == LVAE_ST_ROWMAJOR && !(d.N & 3) && !(d.ldo & 3) && !(d.ldres & 3)) ||
-                     (store == LVAE_ST_SHUFFLE && !(cp & 3));
-    if (vec) {
-        // vector path: per-column ops on the lane's own column, quad transpose, then one 16-B access per 4 outputs
-        const int lj = li & 3;
-        float cbias[C::TN], cgam[C::TN];
-        long ccol4[C::TN];
-        bool cok4[C::TN];
-#pragma unroll
-        for (int b = 0; b < C::TN; ++b) {
-            const int colb = n0 + (wave_n * C::TN + b) * 32;
-            const int col = colb + li;
-            const int cc = col < d.N ? col : 0;
-            cbias[b] = d.bias ? d.bias[cc] : 0.f;
-            cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
-            const int c4 = colb + (li & ~3);                 // first of the 4 columns this lane stores
-            cok4[b] = c4 < d.N;
-            const int c4c = cok4[b] ? c4 : 0;
-            if (store == LVAE_ST_ROWMAJOR) {
-                ccol4[b] = c4c;
-            } else {
-                const int q = c4c / cp, sc = c4c - q * cp, si = q / rr, sj = q - si * rr;
-                ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < C::TM; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;     // row this lane stores
-                const bool rok = row < d.M;
-                const int rowc = rok ? row : 0;
-                long obase;
-                if (store == LVAE_ST_ROWMAJOR) {
-                    obase = (long)rowc * d.ldo;
-                } else {
-                    const int w = rowc % d.W, bh = rowc / d.W, h = bh % d.H, bb = bh / d.H;
-                    obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
-                }
-                const float* resrow = d.res + (long)rowc * d.ldres;
-#pragma unroll
-                for (int b = 0; b < C::TN; ++b) {
-                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
-                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
-                    if (epi == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
-                    else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
-                    quad_transpose(v0, v1, v2, v3, lj);
-                    if (rok && cok4[b]) {
-                        f32x4 o = {v0, v1, v2, v3};
-                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
-                            const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
-                            o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
-                        }
-                        *(f32x4*)(d.out + obase + ccol4[b]) = o;
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // scalar path (final image layer, odd leading dimensions): rows-outer / columns-inner, 4-B accesses
-    float cbias[C::TN], cgam[C::TN];
-    long ccol[C::TN];                 // ROWMAJOR: col; SHUFFLE/IMAGE: column part of the output offset
-    bool cok[C::TN];
-#pragma unroll
-    for (int b = 0; b < C::TN; ++b) {
-        const int col = n0 + (wave_n * C::TN + b) * 32 + li;
-        cok[b] = col < d.N;
-        const int cc = cok[b] ? col : 0;
-        cbias[b] = d.bias ? d.bias[cc] : 0.f;
-        cgam[b] = (epi == LVAE_EPI_GAMMA_RES) ? d.gamma[cc] : 1.f;
-        if (store == LVAE_ST_ROWMAJOR) {
-            ccol[b] = cc;
-        } else if (store == LVAE_ST_SHUFFLE) {        // column n' = (i*r+j)*cp + c
-            const int q = cc / cp, sc = cc - q * cp, si = q / rr, sj = q - si * rr;
-            ccol[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
-        } else {                                      // IMAGE: column n = c*r^2 + i*r + j -> NCHW
-            const int sc = cc / r2, q = cc - sc * r2, si = q / rr, sj = q - si * rr;
-            ccol[b] = ((long)sc * (d.H * rr) + si) * (d.W * rr) + sj;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < C::TM; ++a) {
-        const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            if (row >= d.M) continue;
-            long obase;
-            if (store == LVAE_ST_ROWMAJOR) {
-                obase = (long)row * d.ldo;
-            } else {
-                const int w = row % d.W, bh = row / d.W, h = bh % d.H, bb = bh / d.H;
-                if (store == LVAE_ST_SHUFFLE) obase = (((long)(bb * d.H + h) * rr) * (d.W * rr) + (long)w * rr) * cp;
-                else obase = ((long)bb * cp * (d.H * rr) + (long)h * rr) * (d.W * rr) + (long)w * rr;
-            }
-            const float* resrow = d.res + (long)row * d.ldres;
-#pragma unroll
-            for (int b = 0; b < C::TN; ++b) {
-                if (!cok[b]) continue;
-                float v = acc[a][b][r] + cbias[b];
-                if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
-                else if (epi == LVAE_EPI_GAMMA_RES) v = resrow[ccol[b]] + cgam[b] * v;
-                else if (epi == LVAE_EPI_RES) v = resrow[ccol[b]] + v;
-                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
-                d.out[obase + ccol[b]] = v;
-            }
-        }
-    }
-}
 
 template <class C, int AMODE>
 __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
@@ -810,9 +645,17 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
 
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
+int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
+
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     static bool env_read = false;
-    if (!env_read) { const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e); env_read = true; }
+    static int x3v2 = 1, x3v2_tn = 0;      // tuning hooks: LVAE_X3V2=0 keeps prec 2 on gemm_x3_kernel, LVAE_X3V2_TN forces its tile
+    if (!env_read) {
+        const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e);
+        e = getenv("LVAE_X3V2"); if (e) x3v2 = atoi(e);
+        e = getenv("LVAE_X3V2_TN"); if (e) x3v2_tn = atoi(e);
+        env_read = true;
+    }
     if (!d || !d->A0 || (!d->Wt && !(d->prec != 0 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
     if (d->prec < 0 || d->prec > 2) return -22;
@@ -821,6 +664,10 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
     if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;
     hipStream_t st = (hipStream_t)stream;
+    if (d->prec == 2 && x3v2 && d->cfg == 0 && d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) {   // cfg -1: legacy kernel
+        int rc = 0;
+        if (lvae_gemm_x3v2_try(d, st, x3v2_tn, &rc)) return rc;
+    }
     switch (d->a_mode) {
         case LVAE_A_PLAIN:
             if ((d->K0 & 3) || (d->lda0 & 3) || d->K0 + d->K1 != d->K || (d->K1 && (!d->A1 || (d->lda1 & 3) || (d->K1 & 3))))

@@ -20,11 +20,23 @@ def split_bf16x3(t):
     return torch.stack([hi, mid, lo], 0).contiguous()
 
 
+def pack_bf16x3(t):
+    """The prec-2 weight buffer of lvae_gemm_f32 for an [N][K] fp32 weight: the three bf16 planes hi | mid | lo ([3][N][K]),
+    followed -- when K % 32 == 0 -- by the same values in k16-interleaved order [N][K/16][3][16] (what the double-buffered
+    gemm_x3k16_kernel streams: one 16-deep stage of one row is 96 contiguous bytes)."""
+    planes = split_bf16x3(t)
+    n, k = t.shape
+    if k % 32:
+        return planes.reshape(-1)
+    inter = planes.view(3, n, k // 16, 16).permute(1, 2, 0, 3).contiguous()
+    return torch.cat([planes.reshape(-1), inter.reshape(-1)])
+
+
 def bf16x3_weight_map(tensors):
     keep, amap = [], {}
     for name, t in tensors.items():
         if t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 8 == 0:
-            h = split_bf16x3(t)
+            h = pack_bf16x3(t)
             keep.append(h)
             amap[t.data_ptr()] = h.data_ptr()
     return amap, keep

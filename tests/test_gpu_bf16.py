@@ -95,13 +95,14 @@ def test_gemm_bf16x3_is_fp32_class(M, N, K, epi):
     """prec 2: error against an fp64 reference of the UNROUNDED fp32 operands must be of the same class as the exact fp32
     MFMA path's (<= 2x + 1e-6), on data with a wide dynamic range."""
     from lvae import _native
-    from lvae.models.base import split_bf16x3
+    from lvae.models.base import split_bf16x3, pack_bf16x3
     L = _native.lib()
     g = torch.Generator().manual_seed(M + N + K + 1)
     A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
     Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     W3 = split_bf16x3(Wt)
     assert float((W3.float().sum(0) - Wt).abs().max()) <= 2 ** -24 * float(Wt.abs().max())
+    W3 = pack_bf16x3(Wt)
     bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).cuda()
     ref = A.double() @ Wt.double().t() + bias.double()
@@ -123,3 +124,34 @@ def test_gemm_bf16x3_is_fp32_class(M, N, K, epi):
         errs.append(float((out.double() - ref).abs().max()))
     print(f'M={M} N={N} K={K}: max err fp32-MFMA {errs[0]:.3e}, bf16x3 {errs[1]:.3e}')
     assert errs[1] <= 2 * errs[0] + 1e-6
+
+
+@pytest.mark.parametrize('M,N,K,epi,a_gelu', [(300, 192, 384, 0, 0), (1000, 384, 192, 1, 0), (513, 128, 32, 3, 0), (2048, 448, 256, 2, 0),
+                                              (129, 96, 1024, 0, 0), (4096, 512, 2048, 0, 0), (777, 72, 128, 0, 1), (24576, 1536, 384, 1, 0),
+                                              (6144, 768, 3072, 2, 0), (96, 2048, 512, 0, 1), (128, 64, 64, 0, 0)])
+def test_gemm_x3_pipelined_kernel_is_bit_identical(M, N, K, epi, a_gelu):
+    """gemm_x3v2_kernel (software-pipelined, buffer loads) against gemm_x3_kernel (cfg = -1): same per-accumulator MFMA
+    sequence, so EVERY output bit must match -- the dispatcher may pick either depending on M, and the encoder's and the
+    decoder's priors have to stay identical."""
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    lda = K + 8                                            # padded leading dimension
+    Ab = (torch.randn(M, lda, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    W3 = pack_bf16x3(Wt)
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    outs = []
+    for cfg in (0, -1):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = Ab.data_ptr(), lda, K, Wt.data_ptr(), W3.data_ptr(), K
+        d.bias, d.gamma, d.res, d.ldres, d.out, d.ldo = bias.data_ptr(), gamma.data_ptr(), res.data_ptr(), N, out.data_ptr(), N
+        d.M, d.N, d.K, d.epi, d.prec, d.a_gelu, d.cfg = M, N, K, epi, 2, a_gelu, cfg
+        assert L.lvae_gemm_f32(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])

@@ -23,12 +23,13 @@ def main(path, top=40):
         a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
     fam = [0, 0]
     for name, a in agg.items():
-        if 'gemm_kernel' in name and name.rstrip().endswith(', 0>(lvae_gemm_desc, int, int)'):
+        if (re.search(r'gemm(_x3|_bf16)?_kernel', name) and name.rstrip().endswith(', 0>(lvae_gemm_desc, int, int)')) or \
+                re.search(r'gemm_x3(k16|w8)_kernel', name):
             fam[0] += a[0]; fam[1] += a[1]
     tot = sum(a[1] for a in agg.values())
     print(f'# {path}: {len(rows)} dispatches, total kernel time {tot / 1e6:.3f} ms')
     if fam[0]:
-        print(f'# family gemm_kernel<Cfg<*>, 0> (PLAIN, all tile configs): {fam[0]} calls, avg {fam[1] / fam[0] / 1e3:.2f} us, '
+        print(f'# family gemm[_x3|_bf16]_kernel<Cfg<*>, 0> + gemm_x3k16/x3w8_kernel (PLAIN, all tile configs): {fam[0]} calls, avg {fam[1] / fam[0] / 1e3:.2f} us, '
               f'total {fam[1] / 1e6:.3f} ms  <- compare with bench.py roofline.avg_launch_us')
     print(f'{"calls":>7} {"total_ms":>10} {"avg_us":>10} {"min_us":>9} {"max_us":>9} {"pct":>6}  kernel')
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
