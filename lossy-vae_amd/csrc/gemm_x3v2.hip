@@ -23,6 +23,13 @@
 
 #include <type_traits>
 
+#ifdef LVAE_X3V2_TRACE             // tools/ubench/x3k16_trace.hip: s_memtime stamps of one wave per k16 stage
+extern "C" __device__ long* lvae_trace_buf;
+#define X3_STAMP(i) do { if (tracing) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -302,12 +309,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
     __syncthreads();
 
     bf16x8 af[2][3], bf[2][3];
+#ifdef LVAE_X3V2_TRACE
+    const bool tracing = blockIdx.x == (unsigned)(n_tiles / 2 + 8) && tid == 0;
+    long tstamp[4] = {0, 0, 0, 0};
+    if (tracing) lvae_trace_buf[120] = __builtin_readcyclecounter();
+#endif
     // one k16 stage: compute on stage PAR, write tile q+1 from register set PAR^1 into the other stage, reload that set with q+3
     auto body = [&](auto par_tag, int q) {
         constexpr int PAR = decltype(par_tag)::value, OTH = PAR ^ 1;
         const int q3 = q + 3 < nq ? q + 3 : nq - 1;
         const char* cur = lds + PAR * STAGE;
         char* nxt = lds + OTH * STAGE;
+        X3_STAMP(0);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -352,27 +365,45 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
                 }
                 LVAE_FENCE();
             }
+            if (g == 0) X3_STAMP(1);
         }
+        X3_STAMP(2);
         __syncthreads();
+        X3_STAMP(3);
+#ifdef LVAE_X3V2_TRACE
+        if (tracing && q < 28) for (int z = 0; z < 4; ++z) lvae_trace_buf[q * 4 + z] = tstamp[z];
+#endif
     };
     for (int q = 0; q < nq; q += 2) {
         body(std::integral_constant<int, 0>{}, q);
         body(std::integral_constant<int, 1>{}, q + 1);
     }
+#ifdef LVAE_X3V2_TRACE
+    if (tracing) lvae_trace_buf[121] = __builtin_readcyclecounter();
+#endif
     gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+#ifdef LVAE_X3V2_TRACE
+    if (tracing) lvae_trace_buf[122] = __builtin_readcyclecounter();
+#endif
 }
+
+#ifdef LVAE_X3V2_TRACE
+int g_x3v2_lds_pad = 0;            // trace harness: extra dynamic LDS to force one workgroup per CU
+#else
+constexpr int g_x3v2_lds_pad = 0;
+#endif
 
 template <int TN, bool AGELU>
 int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BN = 64 * TN, LDS = 2 * (128 + BN) * 112;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3k16_kernel<TN, AGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3k16_kernel<TN, AGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 64 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles_m = (d->M + 127) / 128, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU>), dim3(n_tiles), dim3(256), LDS, st, *d, tiles_n, n_tiles);
+    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU>), dim3(n_tiles), dim3(256), LDS + g_x3v2_lds_pad, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -389,7 +420,7 @@ int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* 
     if (sel <= 0) {
         // k16 kernels: rounds of 128 x 64c tiles over 2 x 256 workgroup slots x per-tile work / measured relative efficiency
         double best = 1e300;
-        const double eff[4] = {0, 0.70, 1.00, 0.97};
+        const double eff[4] = {0, 0.70, 1.00, 1.03};
         for (int c = 1; c <= 3; ++c) {
             const long tiles = (long)((M + 127) / 128) * ((N + 64 * c - 1) / (64 * c));
             const long rounds = (tiles + 511) / 512;

@@ -12,6 +12,7 @@
 // accesses, wave64 shuffles for the per-pixel reductions, and >> 256 workgroups per launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lvae_hip.h"
 #include "device_math.h"
@@ -27,12 +28,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // along W in registers: (TW+k-1) input float4 per kernel row feed TW outputs, i.e. ~(TW+k-1)/TW loads per output tap
 // row instead of k.  LayerNorm statistics are reduced across the LPP lanes with xor-shuffles (two-pass variance on the
 // register-resident conv outputs).
-template <int KS, int VPL, int LPP>
+template <int KS, int VPL, int LPP, int TH>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, const float* __restrict__ shift,
                                                         const float* __restrict__ scale1p, float* __restrict__ y,
-                                                        int B, int H, int W, int gpr, long total_groups) {
+                                                        int B, int H, int W, int gpr, int hgr, long total_groups) {
     constexpr int TW = 4;
     constexpr int C = 4 * VPL * LPP;
     constexpr int GPW = 64 / LPP;
@@ -52,25 +53,29 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
     const bool active = g < total_groups;
     const long gg = active ? g : total_groups - 1;
     const int w0 = (int)(gg % gpr) * TW;
-    const long bh = gg / gpr;
-    const int h = (int)(bh % H);
-    const long brow = bh - h;      // b*H
+    const long bhg = gg / gpr;                 // b*hgr + row group
+    const int h0 = (int)(bhg % hgr) * TH;      // first of the TH output rows of this group
+    const long brow = (bhg / hgr) * H;         // b*H
 
-    f32x4 acc[VPL][TW];
+    // Each group produces TH x TW outputs: an input row (TW+k-1 float4 per channel chunk) is loaded ONCE and feeds the
+    // up-to-TH output rows it belongs to.  The 7x7 layers are bound by L2 bandwidth (the k-fold re-reads of the map go to L2,
+    // not HBM: 27 TB/s of 34.5 TB/s measured with TH = 1): TH = 2 cuts the input loads per output from 17.5 to 10.
+    f32x4 acc[VPL][TH][TW];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int c = 4 * (cl + v * LPP);
         const f32x4 bv = *(const f32x4*)(bias + c);
 #pragma unroll
-        for (int t = 0; t < TW; ++t) acc[v][t] = bv;
-        // kernel rows are a RUNTIME loop on purpose: fully unrolled, hipcc hoists all (TW+k-1)*k loads of a channel
+        for (int th = 0; th < TH; ++th)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) acc[v][th][t] = bv;
+        // input rows are a RUNTIME loop on purpose: fully unrolled, hipcc hoists all (TW+k-1)*k loads of a channel
         // chunk to the top and spills kilobytes per lane to scratch (measured: 3.7 KB/lane, 16x slower).
 #pragma unroll 1
-        for (int i = 0; i < KS; ++i) {
-            const int hh = h + i - P;
+        for (int r = 0; r < KS + TH - 1; ++r) {
+            const int hh = h0 + r - P;
             const bool rv = (hh >= 0) && (hh < H);
             const float* xrow = x + ((brow + hh) * W) * (long)C + c;
-            const float* wrow = wt + (long)(i * KS) * C + c;
             f32x4 xr[TW + KS - 1];
 #pragma unroll
             for (int q = 0; q < TW + KS - 1; ++q) {
@@ -79,14 +84,21 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
                 xr[q] = (rv && ww >= 0 && ww < W) ? *(const f32x4*)(xrow + (long)ww * C) : z;
             }
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const f32x4 wv = *(const f32x4*)(wrow + (long)j * C);
+            for (int th = 0; th < TH; ++th) {
+                const int i = r - th;                        // kernel row this input row is for output row h0 + th
+                if (i >= 0 && i < KS) {
+                    const float* wrow = wt + (long)(i * KS) * C + c;
 #pragma unroll
-                for (int t = 0; t < TW; ++t) {
-                    acc[v][t][0] = fmaf(xr[t + j][0], wv[0], acc[v][t][0]);
-                    acc[v][t][1] = fmaf(xr[t + j][1], wv[1], acc[v][t][1]);
-                    acc[v][t][2] = fmaf(xr[t + j][2], wv[2], acc[v][t][2]);
-                    acc[v][t][3] = fmaf(xr[t + j][3], wv[3], acc[v][t][3]);
+                    for (int j = 0; j < KS; ++j) {
+                        const f32x4 wv = *(const f32x4*)(wrow + (long)j * C);
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) {
+                            acc[v][th][t][0] = fmaf(xr[t + j][0], wv[0], acc[v][th][t][0]);
+                            acc[v][th][t][1] = fmaf(xr[t + j][1], wv[1], acc[v][th][t][1]);
+                            acc[v][th][t][2] = fmaf(xr[t + j][2], wv[2], acc[v][th][t][2]);
+                            acc[v][th][t][3] = fmaf(xr[t + j][3], wv[3], acc[v][th][t][3]);
+                        }
+                    }
                 }
             }
         }
@@ -94,62 +106,80 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
 
     const float inv_c = 1.0f / (float)C;
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        float s = 0.f;
+    for (int th = 0; th < TH; ++th) {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) s += (acc[v][t][0] + acc[v][t][1]) + (acc[v][t][2] + acc[v][t][3]);
+        for (int t = 0; t < TW; ++t) {
+            float s = 0.f;
 #pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float mean = s * inv_c;
-        float sq = 0.f;
+            for (int v = 0; v < VPL; ++v) s += (acc[v][th][t][0] + acc[v][th][t][1]) + (acc[v][th][t][2] + acc[v][th][t][3]);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dlt = acc[v][t][e] - mean;
-                acc[v][t][e] = dlt;
-                sq = fmaf(dlt, dlt, sq);
-            }
-        }
-#pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
-        const int ww = w0 + t;
-        if (active && ww < W) {
-            float* yp = y + ((bh * W) + ww) * (long)C;
+            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * inv_c;
+            float sq = 0.f;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
-                const int c = 4 * (cl + v * LPP);
-                f32x4 o4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = acc[v][t][e] * rstd;
-                if (ln_w) {
-                    const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = acc[v][th][t][e] - mean;
+                    acc[v][th][t][e] = dlt;
+                    sq = fmaf(dlt, dlt, sq);
                 }
-                if (shift) {
-                    const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
+            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
+            const int ww = w0 + t, hh = h0 + th;
+            if (active && ww < W && hh < H) {
+                float* yp = y + (((brow + hh) * W) + ww) * (long)C;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int c = 4 * (cl + v * LPP);
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][th][t][e] * rstd;
+                    if (ln_w) {
+                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
+                    }
+                    if (shift) {
+                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
+                    }
+                    *(f32x4*)(yp + c) = o4;
                 }
-                *(f32x4*)(yp + c) = o4;
             }
         }
     }
 }
 
-template <int KS, int VPL, int LPP>
-int launch_dwln(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
-                const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
-    const int gpr = (W + 3) / 4;
-    const long total = (long)B * H * gpr;
+int g_dw_th = 0;       // tuning hook (LVAE_DW_TH): 1 or 2 output rows per group; 0 = heuristic
+
+template <int KS, int VPL, int LPP, int TH>
+int launch_dwln_th(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                   const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+    const int gpr = (W + 3) / 4, hgr = (H + TH - 1) / TH;
+    const long total = (long)B * hgr * gpr;
     const int gpw = 64 / LPP;
     const long waves = (total + gpw - 1) / gpw;
     const long blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL((dwconv_ln_kernel<KS, VPL, LPP>), dim3((unsigned)blocks), dim3(256), 0, st, x, wt, bias, ln_w, ln_b,
-                       shift, scale1p, y, B, H, W, gpr, total);
+    hipLaunchKernelGGL((dwconv_ln_kernel<KS, VPL, LPP, TH>), dim3((unsigned)blocks), dim3(256), 0, st, x, wt, bias, ln_w, ln_b,
+                       shift, scale1p, y, B, H, W, gpr, hgr, total);
     return (int)hipGetLastError();
+}
+
+template <int KS, int VPL, int LPP>
+int launch_dwln(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+    // two output rows per group (measured, B = 8): +12..17 % on the stride-4 maps (C <= 192, ~200k pixels, L2-bandwidth-bound);
+    // slower on the C >= 256 layers, where 200+ VGPRs halve the occupancy.  Same accumulation order => same bits either way.
+    const long px = (long)B * H * W;
+    constexpr int C = 4 * VPL * LPP;
+    int th = g_dw_th ? g_dw_th : ((KS == 7 && C <= 192 && px >= 100000) ? 2 : 1);
+    if (KS == 1) th = 1;
+    if (th == 2) return launch_dwln_th<KS, VPL, LPP, (KS == 1 ? 1 : 2)>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    return launch_dwln_th<KS, VPL, LPP, 1>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
 }
 
 template <int KS>
@@ -354,6 +384,8 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
                                   void* stream) {
     if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
     if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e); env_read = true; }
     hipStream_t st = (hipStream_t)stream;
     switch (k) {
         case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);

@@ -3,6 +3,7 @@
 // Reports cycles per MFMA for F = 0..10.  (Companion of mfma_valu_overlap*.hip, where the VALU work sat in a DIFFERENT wave.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -35,21 +36,25 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, long* cyc,
 
 template <int F>
 void run(const float* in, float* out, long* cyc, int nt) {
-    const int iters = 2000;
+    const int iters = 20000;
     hipLaunchKernelGGL(k<F>, dim3(256), dim3(nt), 0, 0, in, out, cyc, 10);
     hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
     hipLaunchKernelGGL(k<F>, dim3(256), dim3(nt), 0, 0, in, out, cyc, iters);
-    hipDeviceSynchronize();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double tf = 256.0 * (nt / 64) * iters * 8.0 * 32768.0 / (ms * 1e-3) / 1e12;
     long hc[8]; hipMemcpy(hc, cyc + 8 * 100, sizeof(hc), hipMemcpyDeviceToHost);
     long mx = 0; for (int w = 0; w < nt / 64; ++w) mx = hc[w] > mx ? hc[w] : mx;
-    printf("waves/SIMD %d  fillers/MFMA %2d : first wave %.1f, slowest wave %.1f cycles per own MFMA -> %.1f cycles per SIMD-MFMA\n", nt / 256, F,
-           hc[0] / (iters * 8.0), mx / (iters * 8.0), mx / (iters * 8.0) / (nt / 256));
+    printf("waves/SIMD %d  fillers/MFMA %2d : first wave %.1f, slowest wave %.1f cycles per own MFMA -> %.1f cycles per SIMD-MFMA; %.0f TFLOP/s bf16 chip-wide (%.1f us, random operands)\n", nt / 256, F,
+           hc[0] / (iters * 8.0), mx / (iters * 8.0), mx / (iters * 8.0) / (nt / 256), tf, ms * 1e3);
 }
 
 int main() {
     float *in, *out; long* cyc;
     hipMalloc(&in, 4096); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
-    float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (float)(i % 17) * 0.01f;
+    float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
     hipMemcpy(in, h, 4096, hipMemcpyHostToDevice);
     for (int nt = 256; nt <= 512; nt += 256) {
         run<0>(in, out, cyc, nt); run<1>(in, out, cyc, nt); run<2>(in, out, cyc, nt); run<3>(in, out, cyc, nt);
