@@ -1,0 +1,23 @@
+# Round profile set (run on the GPU box from the repo root): writes everything under gpurun_out/prof_round/
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_round
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. default bench line (with cpu_baseline)
+python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+# 2. rocprofv3 kernel stats of the same command shape, product configuration (two pipeline groups / streams)
+rocprofv3 --kernel-trace --stats -d /tmp/pr_a -o a -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_prof_2groups.json 2>/dev/null
+python $R/tools/rocpd_summary.py $(find /tmp/pr_a -name "*.db" | head -1) 40 > $O/kernel_stats_2groups.txt
+# 3. single stream (per-kernel durations not inflated by the other stream): the numbers bench.py's roofline pass must agree with
+LVAE_GROUPS=1 rocprofv3 --kernel-trace --stats -d /tmp/pr_b -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_prof_single_stream.json 2>/dev/null
+python $R/tools/rocpd_summary.py $(find /tmp/pr_b -name "*.db" | head -1) 40 > $O/kernel_stats_single_stream.txt
+# 4. HBM traffic: separate PMC passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+python $R/tools/pmc_traffic.py $(find /tmp/pr_f -name "*.db" | head -1) $(find /tmp/pr_w -name "*.db" | head -1) $O/pmc_gemm_traffic.json > $O/pmc_hbm_traffic.txt
+# 5. other operating points
+python $R/bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-timing > $O/bench_b1.json 2>/dev/null
+python $R/bench.py --batch 4 --height 1216 --width 1216 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_b4_1216.json 2>/dev/null
+python $R/bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32_mode.json 2>/dev/null
+python $R/bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_mode.json 2>/dev/null
+ls -la $O
