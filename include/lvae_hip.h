@@ -164,6 +164,14 @@ int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zha
  * consume a channel count rounded up to a multiple of 4: qres34m z = 14, 10). */
 int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz, void* stream);
 
+/* Sampling branch of a latent block (qarv/model.py:98-100, mode='sampling' with latent=None; conditional_sample /
+ * unconditional_sample :365-404): z = pm + pv * N(0,1) * t + U(-0.5, 0.5) * t, with pm / pv derived from the prior conv output
+ * `prm` exactly as in lvae_prior_index_f32 (pv = exp(softplus(lv + 2.3) - 2.3), NOT lower-bounded).  Device RNG: Philox4x32-10
+ * keyed by `seed`, one counter per element (`offset` + element index), Box-Muller for the normal -- reproducible for a given
+ * (seed, offset) whatever the launch geometry; t = 0 gives z = pm exactly.  z rows have stride ldz >= zdim (pad written as 0). */
+int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdim, int ldz, float t, unsigned long long seed,
+                          unsigned long long offset, void* stream);
+
 /* Eval-mode rate estimate of one latent block (qarv/model.py:95-96 = CompressAI GaussianConditional.forward in eval mode):
  * out_nats[b] += sum over the block's elements of -ln max(P, 1e-9), P = Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s) in fp32 with
  * s from the prior conv output `prm` as in lvae_prior_index_f32; cdf_form 0 = erf (QARV), 1 = erfc (QRes).  sym is in the

@@ -262,6 +262,43 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ Wt,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ prior sampling
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so element e of a launch gets the same variates whatever the grid.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void prior_sample_kernel(const float* __restrict__ prm, float* __restrict__ z, long total, int zdim, int ldz, float t,
+                                    uint64_t seed, uint64_t offset) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*ldz + c
+    if (e >= total) return;
+    const long m = e / ldz;
+    const int c = (int)(e - m * ldz);
+    if (c >= zdim) { z[e] = 0.f; return; }
+    const float mean = prm[m * 2 * zdim + c];
+    const float lv = prm[m * 2 * zdim + zdim + c];
+    const float xs = lv + 2.3f;
+    const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
+    const float pv = expf(sp - 2.3f);
+    const uint64_t ctr = offset + (uint64_t)(m * zdim + c);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float nrm = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+    const float uni = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
+    z[e] = mean + pv * nrm * t + uni * t;
+}
+
 // ------------------------------------------------------------------------------------------------ entropy parameters
 __global__ void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
                                    const float* __restrict__ table, int n_scales, float bound, long total, int HW, int z) {
@@ -481,5 +518,14 @@ extern "C" int lvae_gelu_f32(const float* x, float* y, long n, void* stream) {
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 5; }
+extern "C" int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdim, int ldz, float t, unsigned long long seed,
+                                     unsigned long long offset, void* stream) {
+    if (!prm || !z || M <= 0 || zdim <= 0 || ldz < zdim) return -22;
+    const long total = M * ldz;
+    hipLaunchKernelGGL(prior_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prm, z, total,
+                       zdim, ldz, t, (uint64_t)seed, (uint64_t)offset);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_abi_version(void) { return 6; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

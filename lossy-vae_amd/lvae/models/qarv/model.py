@@ -11,6 +11,7 @@ record the whole network as native HIP launches (lvae/engine.py).  Extension ove
 `decompress_batch` code B images per call (reference: batch 1 only, model.py:521) -- the GPU part runs batched, the
 rANS streams of the B images x 9 latent blocks are coded by parallel host threads.
 """
+import ctypes
 import math
 import os
 import struct
@@ -207,6 +208,7 @@ class _NetPlan(Plan):
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
+        self.prm_ptrs, self.zhat_ptrs, self.zhat_bufs = [], [], []  # per latent block: raw prior conv output / latent buffer (scratch may be re-grown)
         self.lat_shapes = []                    # (z, HW)
 
     def scratch(self, M, C, hid):
@@ -245,6 +247,7 @@ class _NetPlan(Plan):
                   out=prm.data_ptr(), label=p + '.prior')
         pm = self.new(M * z)
         self.pm_bufs.append(pm)
+        self.prm_ptrs.append(prm.data_ptr())
         ioff = sum(s[0] * s[1] for s in self.lat_shapes) * B
         self.lat_shapes.append((z, H * W))
         self.idx_off.append(ioff)
@@ -374,6 +377,7 @@ class _DecPlan(_NetPlan):
         f = self.new(B * h * w * width)
         self.add(lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
         self.cuts = []        # op index after each prior_index (host decode happens there)
+        self.lat_hw = []      # (h, w) of each latent block
         self.out = None
         for i, m in enumerate(model.dec_blocks):
             p = f'dec_blocks.{i}'
@@ -382,7 +386,10 @@ class _DecPlan(_NetPlan):
                 pm, ioff = self.prior(p, m, f.data_ptr(), h, w)
                 self.cuts.append(len(self.ops))
                 self.sym_off.append(ioff)
+                self.lat_hw.append((h, w))
                 zhat = self.buf('zhat', M * z)
+                self.zhat_ptrs.append(zhat.data_ptr())
+                self.zhat_bufs.append(zhat)
                 self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z, z),
                          p + '.dequantize')
                 self.fuse_and_end(p, m, f.data_ptr(), zhat.data_ptr(), h, w)
@@ -662,26 +669,74 @@ class VariableRateLossyVAE(CodecBase):
         return dec.out.clone(), enc.nats.view(self.num_latents, B).clone()
 
     @torch.no_grad()
-    def conditional_sample(self, lmb, latents, **_):
-        """Decoder output for given latents z (qarv/model.py:365-395 with every latent provided, branch :101-103).
-        latents: list of num_latents tensors (B, z_i, h_i, w_i) on the model device whose values are integer + prior-mean,
-        i.e. exactly what the decoder reconstructs.  (Sampling missing latents from the prior is not implemented.)"""
-        assert len(latents) == self.num_latents and all(z is not None for z in latents)
-        B, _, nH, nW = latents[0].shape
+    def conditional_sample(self, lmb, latents, emb=None, bhw_repeat=None, t=1.0, seed=None, return_latents=False):
+        """Decoder output conditioned on a list of latents (qarv/model.py:365-395).  latents[i] is a (B, z_i, h_i, w_i) tensor on
+        the model device (integer + prior mean, what `get_latents` / the decoder produce) or None; a missing latent is drawn from
+        the prior at temperature t, z = pm + pv*N(0,1)*t + U(-.5,.5)*t (:98-100), by the device RNG of `lvae_prior_sample_f32`
+        (Philox4x32-10 keyed by `seed`; default: a fresh seed per call from torch's CPU generator).  t = 0 is deterministic.
+        `emb` is accepted for signature compatibility and must be None (the embedding is always derived from lmb).
+        return_latents=True (not in the reference) also returns the latents actually used, [(B, z_i, h_i, w_i)]."""
+        assert emb is None, 'explicit embeddings are not supported: pass lmb'
+        assert len(latents) == self.num_latents
+        if latents[0] is None:
+            assert bhw_repeat is not None, 'bhw_repeat should be provided'
+            B, nH, nW = bhw_repeat
+        else:
+            B, _, nH, nW = latents[0].shape
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self._prepare(); self._set_lmb(float(lmb))
         pl = self._plan('dec', B, nH, nW)
-        lo = 0
+        st = ctypes.c_void_p(torch.cuda.current_stream(pl.device).cuda_stream)
+        lo, used = 0, []
         for li, cut in enumerate(pl.cuts):
             pl.run(lo, cut)
-            lo = cut
             zdim, hw = pl.lat_shapes[li]
-            pm = pl.pm_bufs[li].view(B, hw, zdim)
-            zt = latents[li].permute(0, 2, 3, 1).reshape(B, hw, zdim)
-            sym = torch.round(zt - pm).to(torch.int32).permute(0, 2, 1).reshape(-1)      # NCHW raster order
-            o = pl.sym_off[li]
-            pl.sym_all[o:o + sym.numel()].copy_(sym)
+            if latents[li] is None:
+                # the launch at `cut` is this block's dequantize: replaced by a draw from the prior written to the same buffer
+                rc = pl.lib.lvae_prior_sample_f32(pl.prm_ptrs[li], pl.zhat_ptrs[li], B * hw, zdim, zdim, float(t),
+                                                  seed, li << 40, st)
+                if rc:
+                    raise RuntimeError(f'lvae_prior_sample_f32 failed: {rc}')
+                lo = cut + 1
+                if return_latents:
+                    zs = pl.zhat_bufs[li][:B * hw * zdim].view(B, hw, zdim)
+                    used.append(zs.permute(0, 2, 1).reshape(B, zdim, *pl.lat_hw[li]).clone())
+            else:
+                assert tuple(latents[li].shape) == (B, zdim, *pl.lat_hw[li]), f'latent {li}: shape {tuple(latents[li].shape)}'
+                pm = pl.pm_bufs[li].view(B, hw, zdim)
+                zt = latents[li].to(pm.device, torch.float32).permute(0, 2, 3, 1).reshape(B, hw, zdim)
+                sym = torch.round(zt - pm).to(torch.int32).permute(0, 2, 1).reshape(-1)      # NCHW raster order
+                o = pl.sym_off[li]
+                pl.sym_all[o:o + sym.numel()].copy_(sym)
+                lo = cut
+                if return_latents:
+                    used.append(latents[li])
         pl.run(lo, None)
-        return pl.out.clone()
+        return (pl.out.clone(), used) if return_latents else pl.out.clone()
+
+    @torch.no_grad()
+    def unconditional_sample(self, lmb, bhw_repeat, t=1.0, seed=None, return_latents=False):
+        """qarv/model.py:397-404: generate images from the prior alone."""
+        return self.conditional_sample(lmb, [None] * self.num_latents, bhw_repeat=bhw_repeat, t=t, seed=seed,
+                                       return_latents=return_latents)
+
+    @torch.no_grad()
+    def get_latents(self, im, lmb=None):
+        """What scripts/qarv/robust-decoding.py reads from forward_end2end(..., get_latent=True) in eval mode
+        (qarv/model.py:94-97,294-315): per latent block the quantized latent z = symbols + prior mean as a (B, z, h, w) tensor and
+        its rate in nats per image, (num_latents, B)."""
+        lmb = lmb or self.default_lmb
+        B, _, H, W = im.shape
+        _, nats = self.estimate(im, lmb)
+        dec = self._plan('dec', B, H // self.max_stride, W // self.max_stride)
+        zs = []
+        for li, (zdim, hw) in enumerate(dec.lat_shapes):
+            o = dec.sym_off[li]
+            sym = dec.sym_all[o:o + B * zdim * hw].view(B, zdim, hw).float()
+            pm = dec.pm_bufs[li].view(B, hw, zdim).permute(0, 2, 1)
+            zs.append((sym + pm).reshape(B, zdim, *dec.lat_hw[li]).contiguous())
+        return zs, nats
 
     @torch.no_grad()
     def _self_evaluate(self, img_paths, lmb: float):

@@ -237,10 +237,15 @@ class QarvOracle:
 
     # ---- decode
     @torch.no_grad()
-    def decode_from_latents(self, lmb, latents):
+    def decode_from_latents(self, lmb, latents, bhw_repeat=None):
         """conditional_sample with given latents (qarv/model.py:365-395, branch :101-103): the decoder
-        output for known z; identical to what decompress() reconstructs."""
-        nB, _, nH, nW = latents[0].shape
+        output for known z; identical to what decompress() reconstructs.
+        A latent given as None is drawn from the prior at temperature t = 0, i.e. z = pm (:98-100 with t = 0):
+        the deterministic form scripts/qarv/robust-decoding.py uses for progressive decoding."""
+        if latents[0] is None:
+            nB, nH, nW = bhw_repeat
+        else:
+            nB, _, nH, nW = latents[0].shape
         emb = lmb_embedding(self.sd, self.arch, lmb, nB)
         feature = self.sd['bias'].expand(nB, -1, nH, nW)
         li = 0
@@ -248,7 +253,7 @@ class QarvOracle:
             p = f'dec_blocks.{i}'
             if b[0] == 'vrlv':
                 feature, pm, pv = self.transform_prior(p, feature, emb)
-                feature = feature + conv(self.sd, f'{p}.z_proj', latents[li])
+                feature = feature + conv(self.sd, f'{p}.z_proj', pm if latents[li] is None else latents[li])
                 li += 1
                 feature = cnx_adaln(self.sd, f'{p}.resnet_end', feature, emb)
             elif b[0] == 'cnx':

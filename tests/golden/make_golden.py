@@ -187,6 +187,29 @@ def golden_imcoding(model):
 
 
 @torch.no_grad()
+def golden_progressive(model, h, w, lmb, tag, img_seed=0):
+    """scripts/qarv/robust-decoding.py:38-56: progressive decoding -- conditional_sample with the first k+1 latents of an encoded
+    image given and the rest drawn from the prior at temperature t = 0 (i.e. z = prior mean: deterministic)."""
+    im, _ = image_tensor(h, w, img_seed)
+    model.eval()
+    _, stats_all = model.forward_end2end(im, lmb=model.expand_to_tensor(lmb, n=1), get_latent=True)
+    L = len(stats_all)
+    out = {'hw': np.array([h, w]), 'img_seed': np.array(img_seed), 'lmb': np.array(float(lmb)),
+           'bits': np.array([float(st['kl'].sum()) / np.log(2) for st in stats_all])}
+    for i, st in enumerate(stats_all):
+        out[f'z{i}'] = npf(st['z'])
+    for anchor in range(L):
+        latents = [st['z'] if i <= anchor else None for i, st in enumerate(stats_all)]
+        x = model.conditional_sample(lmb=lmb, latents=latents, bhw_repeat=(1, h // 64, w // 64), t=0)
+        out[f'x{anchor}'] = npf(x).astype(np.float32)
+    x = model.unconditional_sample(lmb, bhw_repeat=(1, h // 64, w // 64), t=0)
+    out['x_uncond_t0'] = npf(x).astype(np.float32)
+    print('progressive', tag, 'psnr vs input:',
+          [round(float(-10 * np.log10(np.mean((out[f'x{a}'] - npf(im)) ** 2))), 2) for a in range(L)])
+    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}_progressive.npz'), **out)
+
+
+@torch.no_grad()
 def golden_qres(model, h, w, tag, img_seed=0):
     """qres34m (qresvae/model.py:649-725): per-block indexes/symbols/strings, reconstruction, pickle container size."""
     import pickle
@@ -250,6 +273,11 @@ def main_qres():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'qres':
         return main_qres()
+    if len(sys.argv) > 1 and sys.argv[1] == 'progressive':
+        model = lvae.get_model('qarv_base')
+        load_seeded(model, 0)
+        model.eval()
+        return golden_progressive(model, 64, 128, 16.0, '64x128')
     golden_pack()
     golden_cnx_block()
     model = lvae.get_model('qarv_base')

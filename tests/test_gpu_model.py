@@ -261,3 +261,70 @@ def test_max_size_image(product_model):
     assert x.shape == im.shape and bool(torch.isfinite(x).all())
     xe, _ = m.estimate(im, 128.0)
     assert torch.equal(x, xe)
+
+
+def test_progressive_decoding_matches_reference(product_model, golden_dir):
+    """conditional_sample with missing latents at t = 0 (progressive decoding, scripts/qarv/robust-decoding.py:38-56) and
+    unconditional_sample at t = 0 against the reference's outputs; get_latents against forward_end2end(get_latent=True)."""
+    m = product_model
+    g = np.load(os.path.join(golden_dir, 'qarv_base_64x128_progressive.npz'))
+    lmb, (h, w) = float(g['lmb']), g['hw']
+    zs = [torch.from_numpy(g[f'z{i}']).cuda() for i in range(9)]
+    for anchor in range(9):
+        lat = [z if i <= anchor else None for i, z in enumerate(zs)]
+        x = m.conditional_sample(lmb, lat, bhw_repeat=(1, h // 64, w // 64), t=0)
+        assert float((x.cpu() - torch.from_numpy(g[f'x{anchor}'])).abs().max()) <= 1e-4, anchor
+    x = m.unconditional_sample(lmb, bhw_repeat=(1, h // 64, w // 64), t=0)
+    assert float((x.cpu() - torch.from_numpy(g['x_uncond_t0'])).abs().max()) <= 1e-4
+    # latents + rates of the eval-mode forward
+    u8 = seeded_init.synthetic_image_u8(int(h), int(w), int(g['img_seed']))
+    im = torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0).cuda()
+    zs2, nats = m.get_latents(im, lmb)
+    nflip = sum(int(((a.cpu() - torch.from_numpy(g[f'z{i}'])).abs() > 0.5).sum()) for i, a in enumerate(zs2))
+    ntot = sum(a.numel() for a in zs2)
+    assert nflip <= 2e-4 * ntot, (nflip, ntot)
+    bits = nats[:, 0].cpu().numpy() / math.log(2)
+    np.testing.assert_allclose(bits, g['bits'], rtol=2e-3, atol=8.0)
+
+
+def test_prior_sampling_statistics_and_determinism(product_model):
+    """Missing latents are drawn by the device RNG (lvae_prior_sample_f32): same seed -> same image, other seed -> another
+    image, t scales the spread, and the kernel's variates have the moments of pm + pv*N*t + U(-.5,.5)*t."""
+    import ctypes
+    from lvae import _native
+    m = product_model
+    a, za = m.unconditional_sample(64.0, bhw_repeat=(2, 1, 2), t=1e-3, seed=1234, return_latents=True)
+    b, zb = m.unconditional_sample(64.0, bhw_repeat=(2, 1, 2), t=1e-3, seed=1234, return_latents=True)
+    c, zc = m.unconditional_sample(64.0, bhw_repeat=(2, 1, 2), t=1e-3, seed=1235, return_latents=True)
+    z0, zz = m.unconditional_sample(64.0, bhw_repeat=(2, 1, 2), t=0.0, return_latents=True)
+    # (small temperature: with random-init weights the prior scales of the deeper blocks are astronomically large)
+    # (random-init weights give the deeper blocks astronomically large prior scales: only the first blocks are checked)
+    assert a.shape == (2, 3, 64, 128) and len(za) == 9
+    assert all(torch.isfinite(z).all() for z in za[:2])
+    assert all(torch.equal(p, q) for p, q in zip(za[:2], zb[:2]))
+    assert not torch.equal(za[0], zc[0])                  # another seed, other variates
+    assert not torch.equal(za[0][0], za[0][1])            # images of one batch get different variates ...
+    assert torch.equal(zz[0][0], zz[0][1]) and torch.equal(z0[0], z0[1])      # ... and the same prior mean at t = 0
+    assert za[0].shape == (2, 32, 1, 2)
+    # kernel-level moments: pm = 0.25, lv such that pv = exp(softplus(lv + 2.3) - 2.3)
+    L = _native.lib()
+    M, z = 40000, 8
+    lv = 0.7
+    pv = math.exp(math.log1p(math.exp(lv + 2.3)) - 2.3)
+    prm = torch.cat([torch.full((M, z), 0.25), torch.full((M, z), lv)], 1).contiguous().cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for t in (1.0, 0.5):
+        out = torch.empty(M, z, device='cuda')
+        assert L.lvae_prior_sample_f32(prm.data_ptr(), out.data_ptr(), M, z, z, t, 99, 0, st) == 0
+        torch.cuda.synchronize()
+        d = out.double() - 0.25
+        var = (pv * t) ** 2 + t * t / 12.0
+        assert abs(float(d.mean())) < 4 * math.sqrt(var / (M * z))
+        assert abs(float(d.var()) / var - 1) < 0.02
+        # fourth moment of normal + uniform: 3 s^4 + 6 s^2 u^2 + u4 with u^2 = t^2/12, u4 = t^4/80
+        s2, u2, u4 = (pv * t) ** 2, t * t / 12.0, t ** 4 / 80.0
+        assert abs(float((d ** 4).mean()) / (3 * s2 * s2 + 6 * s2 * u2 + u4) - 1) < 0.05
+    out0 = torch.empty(M, z + 2, device='cuda')
+    assert L.lvae_prior_sample_f32(prm.data_ptr(), out0.data_ptr(), M, z, z + 2, 0.0, 99, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out0[:, :z], prm[:, :z]) and float(out0[:, z:].abs().max()) == 0.0

@@ -112,6 +112,20 @@ def test_full_model(golden_dir, oracle_model, tag, seed):
         assert float((x2 - xhat).abs().max()) <= 1e-6
 
 
+def test_progressive_decoding_t0(golden_dir, oracle_model):
+    """scripts/qarv/robust-decoding.py:38-56 on the reference: conditional_sample with the first k+1 latents given and the
+    others at their prior means (t = 0), and unconditional_sample at t = 0."""
+    g = np.load(os.path.join(golden_dir, 'qarv_base_64x128_progressive.npz'))
+    lmb, (h, w) = float(g['lmb']), g['hw']
+    zs = [torch.from_numpy(g[f'z{i}']) for i in range(9)]
+    for anchor in (0, 3, 8):
+        lat = [z if i <= anchor else None for i, z in enumerate(zs)]
+        x = oracle_model.decode_from_latents(lmb, lat, bhw_repeat=(1, h // 64, w // 64))
+        np.testing.assert_allclose(x.numpy(), g[f'x{anchor}'], rtol=0, atol=2e-5)
+    x = oracle_model.decode_from_latents(lmb, [None] * 9, bhw_repeat=(1, h // 64, w // 64))
+    np.testing.assert_allclose(x.numpy(), g['x_uncond_t0'], rtol=0, atol=2e-5)
+
+
 def test_imcoding_evaluate_contract(golden_dir, oracle_model, tmp_path):
     """lvae/evaluation.py:15-67 semantics: bpp over ORIGINAL pixels incl. 4-byte (h,w) header; PSNR on the
     un-rounded float reconstruction; mean of per-image values; ragged sizes padded (coding.py:73-91)."""
