@@ -172,6 +172,18 @@ int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B,
 int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdim, int ldz, float t, unsigned long long seed,
                           unsigned long long offset, void* stream);
 
+/* GaussianNLLOutputNet coding parameters of qres34m_lossless (qresvae/model.py:69-94).  raw = the fused conv_mean | conv_scale
+ * output after PixelShuffle, NHWC [B*H*W][6] (mean c0..2, log-scale c0..2), H x W = image size.  For every (b, c, y, x) in the
+ * coder's NCHW raster order, with bin = 1/127.5 and the reference's fp32 operation order:
+ *   pm  = (rint(m*127.5 + 127.5)/127.5 - 1) / bin          ("workaround to make sure lossless", :72)
+ *   s   = exp(ls - ln(bin));  idx = #{i < n_scales-1 : table[i] < max(s, bound)}          (build_indexes)
+ *   sym = rint(((im - 0.5)*2)/bin - pm)        only when im != NULL (encoder); im is (B,3,H,W) in [0,1]. */
+int lvae_lossless_params_f32(const float* raw, const float* im, float* pm, uint8_t* idx, int32_t* sym, const float* table,
+                             int n_scales, float bound, int B, int H, int W, void* stream);
+
+/* ... and its decoder side (:86-94 + process_output :496-504): out = clamp((sym + pm)*bin, -1, 1)*0.5 + 0.5, NCHW. */
+int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, void* stream);
+
 /* Eval-mode rate estimate of one latent block (qarv/model.py:95-96 = CompressAI GaussianConditional.forward in eval mode):
  * out_nats[b] += sum over the block's elements of -ln max(P, 1e-9), P = Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s) in fp32 with
  * s from the prior conv output `prm` as in lvae_prior_index_f32; cdf_form 0 = erf (QARV), 1 = erfc (QRes).  sym is in the

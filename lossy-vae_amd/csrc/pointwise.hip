@@ -262,6 +262,52 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ Wt,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ lossless output net
+__global__ void lossless_params_kernel(const float* __restrict__ raw, const float* __restrict__ im, float* __restrict__ pm,
+                                       uint8_t* __restrict__ idx, int32_t* __restrict__ sym, const float* __restrict__ table,
+                                       int n_scales, float bound, long total, int HW) {
+#pragma clang fp contract(off)
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = (b*3 + c)*HW + p   (NCHW raster)
+    if (e >= total) return;
+    const long bc = e / HW;
+    const int p = (int)(e - bc * HW);
+    const long b = bc / 3;
+    const int c = (int)(bc - b * 3);
+    const float* r = raw + (b * HW + p) * 6;
+    const float bin = (float)(1.0 / 127.5);
+    float m = r[c] * 127.5f;
+    m = m + 127.5f;
+    m = rintf(m) / 127.5f;
+    m = m - 1.0f;
+    m = m / bin;
+    const float ls = r[3 + c] - (float)(-4.848116360536466);        // - math.log(1/127.5)
+    const float s = fmaxf(expf(ls), bound);
+    int lo = 0, hi = n_scales - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (table[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    pm[e] = m;
+    idx[e] = (uint8_t)lo;
+    if (im) {
+        float x = im[e] - 0.5f;
+        x = x * 2.0f;
+        x = x / bin;
+        sym[e] = (int32_t)rintf(x - m);
+    }
+}
+
+__global__ void lossless_output_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ out, long n) {
+#pragma clang fp contract(off)
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float x = (float)sym[e] + pm[e];
+    x = x * (float)(1.0 / 127.5);
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    x = x * 0.5f;
+    out[e] = x + 0.5f;
+}
+
 // ------------------------------------------------------------------------------------------------ prior sampling
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so element e of a launch gets the same variates whatever the grid.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -527,5 +573,20 @@ extern "C" int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdi
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 6; }
+extern "C" int lvae_lossless_params_f32(const float* raw, const float* im, float* pm, uint8_t* idx, int32_t* sym, const float* table,
+                                        int n_scales, float bound, int B, int H, int W, void* stream) {
+    if (!raw || !pm || !idx || !table || n_scales <= 0 || n_scales > 256 || B <= 0 || H <= 0 || W <= 0 || (im && !sym)) return -22;
+    const long total = (long)B * 3 * H * W;
+    hipLaunchKernelGGL(lossless_params_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, im, pm,
+                       idx, sym, table, n_scales, bound, total, H * W);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, void* stream) {
+    if (!sym || !pm || !out || n <= 0) return -22;
+    hipLaunchKernelGGL(lossless_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_abi_version(void) { return 7; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 
@@ -53,6 +53,8 @@ SIGNATURES = {
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lvae_lossless_params_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    'lvae_lossless_output_f32': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     'lvae_prior_sample_f32': (_i, [_vp, _vp, C.c_long, _i, _i, C.c_float, C.c_ulonglong, C.c_ulonglong, _vp]),
     'lvae_gaussian_nll_f32': (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),

@@ -103,6 +103,22 @@ class _Holder(nn.Module):
     pass
 
 
+class GaussianNLLOutParams(nn.Module):
+    """GaussianNLLOutputNet (:16-94) of qres34m_lossless: conv_mean / conv_scale = patch_upsample(cin, 3, rate 4), and the
+    per-pixel entropy model (stock GaussianConditional, scale_bound 0.11, 128 log-spaced scales 0.11..20: update() :59-67)."""
+    def __init__(self, cin, im_channels=3, rate=4, bin_size=1 / 127.5):
+        super().__init__()
+        from ..qarv.model import UpParams
+        self.conv_mean, self.conv_scale = UpParams(cin, im_channels, rate), UpParams(cin, im_channels, rate)
+        self.cin, self.rate, self.bin_size = cin, rate, bin_size
+        self.discrete_gaussian = DiscretizedGaussian(scale_table=None, cdf_form='erfc', scale_bound=0.11, persistent_table=True)
+        self.discrete_gaussian.register_buffer('scale_bound', torch.Tensor([0.11]))
+
+    def update(self):
+        table = torch.exp(torch.linspace(math.log(0.11), math.log(20), steps=128))
+        self.discrete_gaussian.update_scale_table(table, force=True)
+
+
 # ----------------------------------------------------------------------------------------------- packed weights
 class _Packed:
     def __init__(self, model, dev):
@@ -155,6 +171,18 @@ class _Packed:
                 convw(p + '.z_proj.0', m.z_proj[0], pad_in=zp - m.zdim)
                 convw(p + '.z_proj.2', m.z_proj[2])
         put('bias', model.decoder.bias.reshape(-1))
+        on = model.out_net
+        if isinstance(on, GaussianNLLOutParams):
+            # one GEMM for conv_mean | conv_scale with the PixelShuffle folded into the row order: row (i*r + j)*6 + c is
+            # mean channel c (c < 3) or scale channel c - 3 of sub-pixel (i, j); conv output channel c*r^2 + i*r + j (common.py:33-38)
+            r2 = on.rate ** 2
+            wm, ws = on.conv_mean[0].weight.reshape(3, r2, on.cin), on.conv_scale[0].weight.reshape(3, r2, on.cin)
+            bm, bs = on.conv_mean[0].bias.reshape(3, r2), on.conv_scale[0].bias.reshape(3, r2)
+            put('out_net.w', torch.cat([wm, ws], 0).permute(1, 0, 2).reshape(r2 * 6, on.cin))
+            put('out_net.b', torch.cat([bm, bs], 0).t().reshape(-1))
+            odg = on.discrete_gaussian
+            self.out_scale_table = odg.scale_table.detach().to(**f32).contiguous()
+            self.out_scale_bound = float(odg.lower_bound_scale.bound.item())
         dg = model._dg()
         self.scale_table = dg.scale_table.detach().to(**f32).contiguous()
         self.scale_bound = float(dg.lower_bound_scale.bound.item())
@@ -262,6 +290,30 @@ class _QresPlan(Plan):
             self.gemm(A0=v.data_ptr(), K0=hid // 2, M=M, N=m.width, Wt=pk.p(p + '.z_proj.2.w'), bias=pk.p(p + '.z_proj.2.b'),
                       res=f.data_ptr(), ldres=m.width, out=f.data_ptr(), epi=_native.EPI_RES, label=p + '.z_proj.2')
             self.cnx(p + '.resnet_end', m.resnet_end, f.data_ptr(), f.data_ptr(), h, w)
+        self.lossless = isinstance(model.out_net, GaussianNLLOutParams)
+        if self.lossless:
+            # GaussianNLLOutputNet.compress / decompress (:69-94): per-pixel coding of the 3*H*W image samples
+            on = model.out_net
+            Ho, Wo = h * on.rate, w * on.rate
+            assert (Ho, Wo) == (H, W)
+            raw = self.new(B * Ho * Wo * 6)
+            self.gemm(A0=f.data_ptr(), K0=on.cin, M=B * h * w, N=6 * on.rate ** 2, Wt=pk.p('out_net.w'), bias=pk.p('out_net.b'),
+                      out=raw.data_ptr(), store=_native.ST_SHUFFLE, r=on.rate, H=h, W=w, label='out_net.conv')
+            npx = B * 3 * H * W
+            self.px_pm = self.new(npx)
+            self.px_sym, self.px_idx = self.new(npx, torch.int32), self.new(npx, torch.uint8)
+            self.px_sym_host = torch.empty(npx, dtype=torch.int32).pin_memory()
+            self.px_idx_host = torch.empty(npx, dtype=torch.uint8).pin_memory()
+            self.px_sym_np, self.px_idx_np = self.px_sym_host.numpy(), self.px_idx_host.numpy()
+            self.add(lib.lvae_lossless_params_f32, (raw.data_ptr(), self.im.data_ptr() if encode else None, self.px_pm.data_ptr(),
+                                                    self.px_idx.data_ptr(), self.px_sym.data_ptr() if encode else None,
+                                                    pk.out_scale_table.data_ptr(), pk.out_scale_table.numel(), pk.out_scale_bound,
+                                                    B, H, W), 'out_net.params')
+            if not encode:
+                self.cuts.append(len(self.ops))
+                out = self.new(npx)
+                self.add(lib.lvae_lossless_output_f32, (self.px_sym.data_ptr(), self.px_pm.data_ptr(), out.data_ptr(), npx), 'out_net.output')
+                self.out = out.view(B, 3, H, W)
         if not encode:
             assert self.out is not None
 
@@ -374,6 +426,9 @@ class HierarchicalVAE(CodecBase):
                 else:
                     dg.scale_table = first.scale_table
                     dg._quantized_cdf, dg._offset, dg._cdf_length, dg._host = first._quantized_cdf, first._offset, first._cdf_length, None
+            if isinstance(self.out_net, GaussianNLLOutParams):            # (:645-646)
+                self.out_net.update()
+                self._packed, self._plans = None, {}
         self.compressing = mode
 
     @torch.no_grad()
@@ -394,6 +449,9 @@ class HierarchicalVAE(CodecBase):
             pl.run(stream=stream.cuda_stream)
             pl.sym_host.copy_(pl.sym_all, non_blocking=True)
             pl.idx_host.copy_(pl.idx_all, non_blocking=True)
+            if pl.lossless:
+                pl.px_sym_host.copy_(pl.px_sym, non_blocking=True)
+                pl.px_idx_host.copy_(pl.px_idx, non_blocking=True)
             stream.synchronize()
             sv, iv = [], []
             for b in range(n):
@@ -402,7 +460,15 @@ class HierarchicalVAE(CodecBase):
                     sv.append(pl.sym_np[o:o + z * hw]); iv.append(pl.idx_np[o:o + z * hw])
             strings = rans_encode_streams(tables, sv, iv, nthreads)
             nl = len(pl.lat_shapes)
-            return [[[s] for s in strings[b * nl:(b + 1) * nl]] + [(1, width, H // 64, W // 64)] for b in range(n)]
+            objs = [[[s] for s in strings[b * nl:(b + 1) * nl]] + [(1, width, H // 64, W // 64)] for b in range(n)]
+            if pl.lossless:                                  # final string of the output net (:664-667)
+                px = 3 * H * W
+                fin = rans_encode_streams(self.out_net.discrete_gaussian.host_tables(),
+                                          [pl.px_sym_np[b * px:(b + 1) * px] for b in range(n)],
+                                          [pl.px_idx_np[b * px:(b + 1) * px] for b in range(n)], nthreads)
+                for b in range(n):
+                    objs[b].append([fin[b]])
+            return objs
 
         out = []
         for part in self._run_groups(encode_group, groups):
@@ -418,8 +484,10 @@ class HierarchicalVAE(CodecBase):
     @torch.no_grad()
     def decompress_batch(self, objs):
         B = len(objs)
-        shape = tuple(objs[0][-1])
-        assert all(tuple(o[-1]) == shape for o in objs) and shape[0] == 1
+        lossless = isinstance(self.out_net, GaussianNLLOutParams)
+        si = -2 if lossless else -1                          # position of the feature-shape tuple (:660-667)
+        shape = tuple(objs[0][si])
+        assert all(tuple(o[si]) == shape for o in objs) and shape[0] == 1
         nH, nW = shape[2], shape[3]
         H, W = nH * 64, nW * 64
         self._prepare()
@@ -435,6 +503,15 @@ class HierarchicalVAE(CodecBase):
             for li, cut in enumerate(pl.cuts):
                 pl.run(lo, cut, stream=stream.cuda_stream)
                 lo = cut
+                if pl.lossless and li == len(pl.cuts) - 1:   # the per-pixel stream of the output net (:680-682)
+                    px = 3 * H * W
+                    pl.px_idx_host.copy_(pl.px_idx, non_blocking=True)
+                    stream.synchronize()
+                    rans_decode_streams(self.out_net.discrete_gaussian.host_tables(), [objs[start + b][-1][0] for b in range(n)],
+                                        [pl.px_idx_np[b * px:(b + 1) * px] for b in range(n)],
+                                        [pl.px_sym_np[b * px:(b + 1) * px] for b in range(n)], nthreads)
+                    pl.px_sym.copy_(pl.px_sym_host, non_blocking=True)
+                    continue
                 z, hw = pl.lat_shapes[li]
                 o, cnt = pl.idx_off[li], n * z * hw
                 pl.idx_host[o:o + cnt].copy_(pl.idx_all[o:o + cnt], non_blocking=True)

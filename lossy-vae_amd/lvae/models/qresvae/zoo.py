@@ -37,3 +37,36 @@ def qres34m(lmb=32, pretrained=False):
     else:
         assert pretrained is False, f'Invalid {pretrained=} and {lmb=}'
     return model
+
+
+@register_model
+def qres34m_lossless(pretrained=False):
+    """(reference zoo.py:63-118): the qres34m backbone without its final patch_upsample; GaussianNLLOutputNet codes the
+    3*H*W image samples per pixel (1.18 M symbols for 512x768) on top of the 12 latent strings => lossless."""
+    ch = 96
+    enc_nums, dec_nums, z_dims = [6, 6, 6, 4, 2], [1, 2, 3, 3, 3], [16, 14, 12, 10, 8]
+    enc_k, dec_k = [7, 7, 5, 3, 1], [1, 3, 5, 7, 7]
+    enc_w = [ch * 2, ch * 4, ch * 4, ch * 4, ch * 4]
+    dec_w = [ch * 4, ch * 4, ch * 4, ch * 4, ch * 2]
+    enc = [qres.StemParams(3, enc_w[0], 4)]
+    for lvl in range(5):
+        enc += [qres.MyCNXParams(enc_w[lvl], kernel_size=enc_k[lvl]) for _ in range(enc_nums[lvl])]
+        if lvl < 4:
+            enc.append(qres.MyCNXDownParams(enc_w[lvl], enc_w[lvl + 1]))
+    dec = []
+    for lvl in range(5):
+        dec += [qres.QLBParams(dec_w[lvl], z_dims[lvl], kernel_size=dec_k[lvl]) for _ in range(dec_nums[lvl])]
+        if lvl < 4:
+            dec.append(UpParams(dec_w[lvl], dec_w[lvl + 1], 2))
+    cfg = dict(enc_blocks=enc, dec_blocks=dec, out_net=qres.GaussianNLLOutParams(ch * 2, 3, rate=4),
+               im_shift=-0.4546259594901961, im_scale=3.67572653978347, max_stride=64)
+    model = qres.HierarchicalVAE(cfg)
+    if pretrained is True:
+        from torch.hub import load_state_dict_from_url
+        url = 'https://huggingface.co/duanzh0/my-model-weights/resolve/main/qres34m/qres34m-lossless.pt'
+        model.load_state_dict(load_state_dict_from_url(url)['model'])
+    elif isinstance(pretrained, str):
+        model.load_state_dict(torch.load(pretrained)['model'])
+    else:
+        assert pretrained is False, f'Invalid {pretrained=}'
+    return model

@@ -38,6 +38,14 @@ def qres34m_arch():
     return dict(enc=enc, dec=dec, im_shift=-0.4546259594901961, im_scale=3.67572653978347, max_stride=64)
 
 
+def qres34m_lossless_arch():
+    """zoo.py:63-118: the qres34m backbone without its last patch_upsample, plus GaussianNLLOutputNet."""
+    a = qres34m_arch()
+    a['dec'] = a['dec'][:-1]
+    a['out_net'] = dict(cin=192, rate=4, bin_size=1 / 127.5)
+    return a
+
+
 def _cnx_shapes(p, dim, k, mlp_ratio=2):
     hid = int(mlp_ratio * dim)
     return [(f'{p}.conv_dw.weight', (dim, 1, k, k)), (f'{p}.conv_dw.bias', (dim,)), (f'{p}.norm.weight', (dim,)),
@@ -75,6 +83,10 @@ def qres_param_shapes(arch):
             out += [(f'{p}.z_proj.0.weight', (hid // 2, z, kk, kk)), (f'{p}.z_proj.0.bias', (hid // 2,)),
                     (f'{p}.z_proj.2.weight', (w, hid // 2, 1, 1)), (f'{p}.z_proj.2.bias', (w,))]
     out += [('decoder.bias', (1, arch['dec'][0][1], 1, 1))]
+    if 'out_net' in arch:
+        o = arch['out_net']
+        for n in ('conv_mean', 'conv_scale'):
+            out += [(f'out_net.{n}.0.weight', (3 * o['rate'] ** 2, o['cin'], 1, 1)), (f'out_net.{n}.0.bias', (3 * o['rate'] ** 2,))]
     return out
 
 
@@ -123,6 +135,11 @@ class QresOracle:
             scale_table = torch.exp(torch.linspace(math.log(0.1), math.log(20), steps=64))
             self.dg.update_scale_table(scale_table)
             self.dg.update()
+            if 'out_net' in self.arch:                                                     # GaussianNLLOutputNet.update (:59-67)
+                self.out_dg = cs.GaussianConditional(None, scale_bound=0.11)
+                lower = self.out_dg.lower_bound_scale.bound.item()
+                self.out_dg.update_scale_table(torch.exp(torch.linspace(math.log(lower), math.log(20), steps=128)))
+                self.out_dg.update()
 
     def encoder(self, x):                                                                  # model.py:200-207
         feats = {}
@@ -173,13 +190,35 @@ class QresOracle:
                 feature = F.pixel_shuffle(conv(self.sd, f'{p}.0', feature), b[3])
         return dict(enc_features=feats, blocks=blocks, smallest=tuple(feats[min_res].shape), feature=feature)
 
+    def _prepare_codec(self, feature, x=None):                                             # model.py:69-80
+        o = self.arch['out_net']
+        pm = F.pixel_shuffle(conv(self.sd, 'out_net.conv_mean.0', feature), o['rate'])
+        pm = torch.round(pm * 127.5 + 127.5) / 127.5 - 1
+        plogv = F.pixel_shuffle(conv(self.sd, 'out_net.conv_scale.0', feature), o['rate'])
+        pm = pm / o['bin_size']
+        plogv = plogv - math.log(o['bin_size'])
+        if x is not None:
+            x = x / o['bin_size']
+        return pm, plogv, x
+
     @torch.no_grad()
-    def compress(self, im):                                                                # model.py:649-668
+    def compress(self, im, trace=None):                                                    # model.py:649-668
         tr = self.encode_trace(im, code=True)
-        return [blk['strings'] for blk in tr['blocks']] + [tr['smallest']]
+        obj = [blk['strings'] for blk in tr['blocks']] + [tr['smallest']]
+        if 'out_net' in self.arch:                                                         # :664-667, :82-86
+            x_tgt = (im - 0.5) * 2.0                                                       # preprocess_target :506-515
+            pm, plogv, x = self._prepare_codec(tr['feature'], x_tgt)
+            indexes = self.out_dg.build_indexes(torch.exp(plogv))
+            if trace is not None:
+                trace.update(pm=pm, indexes=indexes, symbols=self.out_dg.quantize(x, 'symbols', pm))
+            obj.append(self.out_dg.compress(x, indexes, means=pm))
+        return obj
 
     @torch.no_grad()
     def decompress(self, obj):                                                             # model.py:670-687, 440-454
+        final = None
+        if 'out_net' in self.arch:
+            obj, final = obj[:-1], obj[-1]
         feature = self.sd['decoder.bias'].expand(obj[-1])
         si = 0
         for i, b in enumerate(self.arch['dec']):
@@ -194,4 +233,8 @@ class QresOracle:
             else:
                 feature = F.pixel_shuffle(conv(self.sd, f'{p}.0', feature), b[3])
         assert si == len(obj) - 1
+        if final is not None:                                                              # :88-94
+            pm, plogv, _ = self._prepare_codec(feature)
+            indexes = self.out_dg.build_indexes(torch.exp(plogv))
+            feature = self.out_dg.decompress(final, indexes, means=pm) * self.arch['out_net']['bin_size']
         return feature.clone().clamp_(min=-1.0, max=1.0).mul_(0.5).add_(0.5)               # model.py:496-504

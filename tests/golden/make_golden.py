@@ -255,6 +255,49 @@ def golden_qres(model, h, w, tag, img_seed=0):
     np.savez_compressed(os.path.join(HERE, f'qres34m_{tag}.npz'), **out)
 
 
+@torch.no_grad()
+def golden_qres_lossless(model, h, w, tag, img_seed=0):
+    """qres34m_lossless (qresvae/zoo.py:63-118, model.py:16-94,649-687): the 12 latent strings as for qres34m plus the final
+    per-pixel string of GaussianNLLOutputNet (3*H*W symbols, 128-entry scale table); the decode must be bit-exact."""
+    import pickle
+    im, u8 = image_tensor(h, w, img_seed)
+    out = {'hw': np.array([h, w]), 'img_seed': np.array(img_seed)}
+    on = model.out_net
+    rec = {}
+    dg = on.discrete_gaussian
+    orig_bi, orig_c = dg.build_indexes, dg.compress
+
+    def bi(sc):
+        idx = orig_bi(sc)
+        rec['scale'], rec['indexes'] = npf(sc), npf(idx).astype(np.uint8)
+        return idx
+
+    def comp(x, indexes, means=None):
+        rec['pm'] = npf(means)
+        rec['symbols'] = npf(dg.quantize(x, 'symbols', means)).astype(np.int32)
+        s = orig_c(x, indexes, means=means)
+        rec['string'] = np.frombuffer(s[0], dtype=np.uint8)
+        return s
+    dg.build_indexes, dg.compress = bi, comp
+    obj = model.compress(im)
+    dg.build_indexes, dg.compress = orig_bi, orig_c
+    for k, v in rec.items():
+        out[f'out.{k}'] = v
+    for i, s in enumerate(obj[:-2]):
+        out[f'string{i}'] = np.frombuffer(s[0], dtype=np.uint8)
+    out['smallest'] = np.array(obj[-2])
+    out['pickle_bytes'] = np.array(len(pickle.dumps(obj + [(h, w)])))
+    xhat = model.decompress(obj)
+    out['xhat'] = npf(xhat)
+    back = torch.round(xhat * 255.0).to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    out['lossless'] = np.array(bool((back == u8).all()))
+    out['scale_table'] = npf(dg.scale_table)
+    print('qres34m_lossless', tag, 'latent bytes', sum(len(s[0]) for s in obj[:-2]), 'pixel-stream bytes', len(obj[-1][0]),
+          'bpp', 8 * (sum(len(s[0]) for s in obj[:-2]) + len(obj[-1][0])) / (h * w), 'lossless', bool(out['lossless']),
+          'sym range', int(rec['symbols'].min()), int(rec['symbols'].max()), 'idx range', int(rec['indexes'].min()), int(rec['indexes'].max()))
+    np.savez_compressed(os.path.join(HERE, f'qres34m_lossless_{tag}.npz'), **out)
+
+
 def main_qres():
     model = lvae.get_model('qres34m')
     load_seeded(model, 0)
@@ -273,6 +316,14 @@ def main_qres():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'qres':
         return main_qres()
+    if len(sys.argv) > 1 and sys.argv[1] == 'lossless':
+        model = lvae.get_model('qres34m_lossless')
+        load_seeded(model, 0)
+        model.eval()
+        model.compress_mode()
+        with open(os.path.join(HERE, 'qres34m_lossless_state_keys.json'), 'w') as f:
+            json.dump({k: list(v.shape) for k, v in model.state_dict().items() if 'discrete_gaussian' not in k}, f)
+        return golden_qres_lossless(model, 64, 128, '64x128')
     if len(sys.argv) > 1 and sys.argv[1] == 'progressive':
         model = lvae.get_model('qarv_base')
         load_seeded(model, 0)

@@ -127,3 +127,91 @@ def test_hip_file_round_trip_and_batch(product, tmp_path):
         assert objs[i] == product.compress(ims[i:i + 1])
     xb = product.decompress_batch(objs)
     assert torch.equal(xb[2:3], product.decompress(objs[2]))
+
+
+# ----------------------------------------------------------------------------------- qres34m_lossless
+@pytest.fixture(scope='module')
+def lossless_sd():
+    return seeded_init.seeded_state_dict(qres_oracle.qres_param_shapes(qres_oracle.qres34m_lossless_arch()), seed=0)
+
+
+def test_lossless_inventory(lossless_sd, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, 'qres34m_lossless_state_keys.json')))
+    assert {k: list(v.shape) for k, v in lossless_sd.items()} == ref
+    import lvae
+    m = lvae.get_model('qres34m_lossless')
+    own = {k: list(v.shape) for k, v in m.state_dict().items() if 'discrete_gaussian' not in k}
+    assert own == ref
+
+
+def test_lossless_oracle_matches_reference(golden_dir, lossless_sd):
+    """GaussianNLLOutputNet.compress/decompress (qresvae/model.py:69-94): per-pixel means / scale indexes / symbols and the
+    final string against the reference; the decode is bit-exact (the reference's evaluate-lossless.py assertion)."""
+    g = np.load(os.path.join(golden_dir, 'qres34m_lossless_64x128.npz'))
+    h, w = g['hw'].tolist()
+    o = qres_oracle.QresOracle(lossless_sd, arch=qres_oracle.qres34m_lossless_arch())
+    o.compress_mode()
+    np.testing.assert_allclose(o.out_dg.scale_table.numpy(), g['scale_table'], rtol=1e-6)
+    u8 = seeded_init.synthetic_image_u8(h, w, int(g['img_seed']))
+    im = torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
+    tr = {}
+    obj = o.compress(im, trace=tr)
+    assert len(obj) == 14 and tuple(obj[-2]) == tuple(g['smallest'].tolist())
+    lat_same = all(obj[i][0] == g[f'string{i}'].tobytes() for i in range(12))
+    n = tr['symbols'].numel()
+    flips = int((tr['symbols'].numpy() != g['out.symbols']).sum()) + int((tr['indexes'].numpy() != g['out.indexes']).sum())
+    assert flips <= (0 if lat_same else 0.05) * n, (flips, n)
+    if lat_same:
+        assert obj[-1][0] == g['out.string'].tobytes()
+        assert len(pickle.dumps(obj + [(h, w)])) == int(g['pickle_bytes'])
+    xhat = o.decompress(obj)
+    assert np.array_equal(torch.round(xhat * 255.0).to(torch.uint8)[0].permute(1, 2, 0).numpy(), u8)      # lossless
+    assert bool(g['lossless'])
+
+
+@pytest.fixture(scope='module')
+def lossless_product(lossless_sd):
+    import lvae
+    m = lvae.get_model('qres34m_lossless')
+    full = m.state_dict()
+    for k, v in lossless_sd.items():
+        full[k] = torch.from_numpy(v)
+    m.load_state_dict(full)
+    m.compress_mode()
+    return m.to('cuda:0').eval()
+
+
+@pytest.mark.gpu
+def test_lossless_hip_matches_reference_and_is_lossless(golden_dir, lossless_product, tmp_path):
+    from PIL import Image
+    m = lossless_product
+    g = np.load(os.path.join(golden_dir, 'qres34m_lossless_64x128.npz'))
+    h, w = g['hw'].tolist()
+    u8 = seeded_init.synthetic_image_u8(h, w, int(g['img_seed']))
+    im = torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0).cuda()
+    obj = m.compress(im)
+    assert len(obj) == 14 and tuple(obj[-2]) == tuple(g['smallest'].tolist())
+    lat_same = all(obj[i][0] == g[f'string{i}'].tobytes() for i in range(12))
+    pl = m._plan('enc', 1, h, w)
+    sym, idx, pm = pl.px_sym.cpu().numpy().reshape(1, 3, h, w), pl.px_idx.cpu().numpy().reshape(1, 3, h, w), pl.px_pm.cpu().numpy().reshape(1, 3, h, w)
+    n = sym.size
+    flips = int((sym != g['out.symbols']).sum()) + int((idx != g['out.indexes']).sum())
+    print(f'qres34m_lossless: latent strings identical: {lat_same}; pixel stream flips {flips} of {n}; max|dpm| {np.abs(pm - g["out.pm"]).max()}')
+    assert flips <= (2e-4 if lat_same else 0.05) * n
+    if lat_same and flips == 0:
+        assert obj[-1][0] == g['out.string'].tobytes()
+        assert len(pickle.dumps(obj + [(h, w)])) == int(g['pickle_bytes'])
+    xhat = m.decompress(obj)
+    assert np.array_equal(torch.round(xhat * 255.0).to(torch.uint8)[0].permute(1, 2, 0).cpu().numpy(), u8)           # lossless
+    # files + batches (scripts/qresvae/evaluate-lossless.py:21-30), ragged size -> padded, cropped back, still exact
+    u2 = seeded_init.synthetic_image_u8(100, 70, 21)
+    Image.fromarray(u2).save(tmp_path / 'a.png')
+    m.compress_file(tmp_path / 'a.png', tmp_path / 'a.bits')
+    fake = m.decompress_file(tmp_path / 'a.bits').squeeze(0).cpu()
+    assert np.array_equal(torch.round(fake * 255.0).to(torch.uint8).permute(1, 2, 0).numpy(), u2)
+    ims = torch.cat([torch.from_numpy(seeded_init.synthetic_image_u8(64, 128, s)).permute(2, 0, 1).float().div(255).unsqueeze(0)
+                     for s in (31, 32, 33)], 0).cuda()
+    objs = m.compress_batch(ims)
+    assert objs[1] == m.compress(ims[1:2])
+    xb = m.decompress_batch(objs)
+    assert torch.equal(torch.round(xb * 255.0), torch.round(ims * 255.0))
