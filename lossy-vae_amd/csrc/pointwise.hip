@@ -176,8 +176,8 @@ int launch_dwln(const float* x, const float* wt, const float* bias, const float*
     // slower on the C >= 256 layers, where 200+ VGPRs halve the occupancy.  Same accumulation order => same bits either way.
     const long px = (long)B * H * W;
     constexpr int C = 4 * VPL * LPP;
-    int th = g_dw_th ? g_dw_th : ((KS == 7 && C <= 192 && px >= 100000) ? 2 : 1);
-    if (KS == 1) th = 1;
+    int th = g_dw_th ? g_dw_th : ((KS == 7 && C <= 192 && VPL <= 3 && px >= 100000) ? 2 : 1);
+    if (KS == 1 || VPL > 4) th = 1;          // VPL = 9 (C = 144, 288) has no registers for a second row
     if (th == 2) return launch_dwln_th<KS, VPL, LPP, (KS == 1 ? 1 : 2)>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
     return launch_dwln_th<KS, VPL, LPP, 1>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
 }
@@ -187,6 +187,8 @@ int dispatch_dwln_c(int C, const float* x, const float* wt, const float* bias, c
                     const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
     switch (C) {
         case 128: return launch_dwln<KS, 2, 16>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 144: return launch_dwln<KS, 9, 4>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);      // qres17m
+        case 288: return launch_dwln<KS, 9, 8>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 192: return launch_dwln<KS, 3, 16>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 256: return launch_dwln<KS, 2, 32>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 384: return launch_dwln<KS, 3, 32>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -481,7 +483,7 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
 
 extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out, int B, int H, int W,
                              int Cout, float im_shift, float im_scale, void* stream) {
-    if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256 || (Cout & 63)) return -22;
+    if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256) return -22;
     const long M = (long)B * (H / 4) * (W / 4);
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
                        B, H, W, Cout, im_shift, im_scale, M);

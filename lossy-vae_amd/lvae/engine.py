@@ -94,7 +94,7 @@ class Plan:
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, label='gemm'):
         if K is None:
             K = K0 + K1
         if Wt16 is None and self.w16 is not None:
@@ -110,7 +110,9 @@ class Plan:
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
         d.cfg = 0
         d.a_gelu = a_gelu
-        d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0) else 0    # bf16 / bf16x3 only when the plan provides the bf16 planes
+        # bf16 / bf16x3 only when the plan provides the bf16 planes; exact=True forces the fp32 MFMA (pure data-movement GEMMs with
+        # 0/1 weights: nearest upsampling, space-to-depth -- x*1 + 0*... must reproduce x bit for bit)
+        d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
         d.Wt16 = Wt16 if d.prec else None
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

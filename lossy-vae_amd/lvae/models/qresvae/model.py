@@ -48,13 +48,32 @@ class MyCNXParams(nn.Module):
         self.gamma = nn.Parameter(1e-6 * torch.ones(dim))
 
 
+class DeconvParams(nn.ConvTranspose2d):
+    """common.deconv (common.py:40-45): ConvTranspose2d(k, stride 2, padding k//2, output_padding 1): doubles the resolution."""
+    kind = 'deconv'
+
+    def __init__(self, cin, cout, kernel_size=5):
+        super().__init__(cin, cout, kernel_size=kernel_size, stride=2, output_padding=1, padding=kernel_size // 2)
+        self.cin, self.cout, self.k, self.rate = cin, cout, kernel_size, 2
+
+
+class NearestUpParams(nn.Upsample):
+    """torch.nn.Upsample(scale_factor=s), nearest (qres17m, zoo.py:143)."""
+    kind = 'nearest'
+
+    def __init__(self, scale_factor):
+        super().__init__(scale_factor=scale_factor)
+        self.rate = int(scale_factor)
+
+
 class MyCNXDownParams(MyCNXParams):
     kind = 'cnxdown'
 
-    def __init__(self, in_ch, out_ch, kernel_size=7):
+    def __init__(self, in_ch, out_ch, kernel_size=7, down_rate=2):
         super().__init__(in_ch, kernel_size)
-        self.downsapmle = _conv(in_ch, out_ch, 2, 2, 0)          # [sic] reference attribute name (:187)
-        self.out_ch = out_ch
+        assert down_rate in (2, 4)
+        self.downsapmle = _conv(in_ch, out_ch, down_rate, down_rate, 0)          # [sic] reference attribute name (:187)
+        self.out_ch, self.down_rate = out_ch, down_rate
 
 
 class StemParams(nn.Conv2d):
@@ -136,12 +155,15 @@ class _Packed:
             put(p + '.fc2_w', m.mlp.fc2.weight); put(p + '.fc2_b', m.mlp.fc2.bias)
             put(p + '.gamma', m.gamma.reshape(C))
 
-        def convw(name, c, pad_in=0):
-            w = c.weight
+        def convw(name, c, pad_in=0, pad_out=0):
+            w, b = c.weight, c.bias
             if pad_in:
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad_in))        # zero weights for padded input channels
+            if pad_out:                                                         # zero rows: padded output channels are exactly 0
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad_out))
+                b = torch.nn.functional.pad(b, (0, pad_out))
             put(name + '.w', w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))     # [Cout][(i,j,ci)]  (== [Cout][Cin] for 1x1)
-            put(name + '.b', c.bias)
+            put(name + '.b', b)
 
         def vd(p, m):
             for n in ('c1', 'c2', 'c3', 'c4'):
@@ -153,8 +175,16 @@ class _Packed:
                 put(p + '.w', m.weight.reshape(m.out_channels, -1).t()); put(p + '.b', m.bias)
             else:
                 cnx(p, m)
-                if m.kind == 'cnxdown':
+                if m.kind == 'cnxdown' and m.down_rate == 2:
                     convw(p + '.downsapmle', m.downsapmle)
+                elif m.kind == 'cnxdown':
+                    # 4x4/s4 conv as two 2x2 patch gathers: an exact space-to-depth (identity weights, channel order (i, j, ci))
+                    # and a 2x2/s2 conv over the 4C-channel map whose k index (I, J, i, j, ci) is input pixel (2I+i, 2J+j)
+                    C, w = m.dim, m.downsapmle.weight                           # [Cout][C][4][4]
+                    put(p + '.s2d.w', torch.eye(4 * C)); put(p + '.s2d.b', torch.zeros(4 * C))
+                    w6 = w.reshape(w.shape[0], C, 2, 2, 2, 2)                   # [n][ci][I][i][J][j]
+                    put(p + '.downsapmle.w', w6.permute(0, 2, 4, 3, 5, 1).reshape(w.shape[0], 16 * C))
+                    put(p + '.downsapmle.b', m.downsapmle.bias)
         for i, m in enumerate(model.decoder.dec_blocks):
             p = f'decoder.dec_blocks.{i}'
             if m.kind == 'up':
@@ -164,12 +194,29 @@ class _Packed:
                     w = w.reshape(m.cout, r2, m.cin).permute(1, 0, 2).reshape(r2 * m.cout, m.cin)
                     b = b.reshape(m.cout, r2).t().reshape(-1)
                 put(p + '.w', w); put(p + '.b', b)
+            elif m.kind == 'deconv':
+                # stride-2 transposed conv as ONE 3x3-gather GEMM with a PixelShuffle store: output pixel (2a+py, 2b+px) reads the
+                # input pixels (a+di, b+dj), di, dj in {-1, 0, 1}, through kernel tap (py + p - 2 di, px + p - 2 dj) when it exists
+                k, pd, cin, cout = m.k, m.k // 2, m.cin, m.cout
+                wt = m.weight                                                   # [Cin][Cout][k][k]
+                wp = torch.zeros(2, 2, cout, 3, 3, cin, dtype=wt.dtype)
+                for py in range(2):
+                    for px in range(2):
+                        for di in (-1, 0, 1):
+                            for dj in (-1, 0, 1):
+                                ky, kx = py + pd - 2 * di, px + pd - 2 * dj
+                                if 0 <= ky < k and 0 <= kx < k:
+                                    wp[py, px, :, di + 1, dj + 1, :] = wt[:, :, ky, kx].t()
+                put(p + '.w', wp.reshape(4 * cout, 9 * cin)); put(p + '.b', m.bias.repeat(4))
+            elif m.kind == 'nearest':
+                C, r2 = m.channels, m.rate ** 2
+                put(p + '.w', torch.eye(C).repeat(r2, 1)); put(p + '.b', torch.zeros(r2 * C))
             else:
                 cnx(p + '.resnet_front', m.resnet_front); cnx(p + '.resnet_end', m.resnet_end)
                 vd(p + '.posterior', m.posterior); vd(p + '.prior', m.prior)
-                zp = (m.zdim + 3) // 4 * 4
-                convw(p + '.z_proj.0', m.z_proj[0], pad_in=zp - m.zdim)
-                convw(p + '.z_proj.2', m.z_proj[2])
+                zp, hp = (m.zdim + 3) // 4 * 4, (m.hid // 2 + 3) // 4 * 4      # GEMM K must be a multiple of 4 (16-B operand loads)
+                convw(p + '.z_proj.0', m.z_proj[0], pad_in=zp - m.zdim, pad_out=hp - m.hid // 2)
+                convw(p + '.z_proj.2', m.z_proj[2], pad_in=hp - m.hid // 2)
         put('bias', model.decoder.bias.reshape(-1))
         on = model.out_net
         if isinstance(on, GaussianNLLOutParams):
@@ -216,8 +263,8 @@ class _QresPlan(Plan):
         for m in model.decoder.dec_blocks:
             if m.kind == 'qlb':
                 tot += m.zdim * nH * s * nW * s
-            elif m.rate == 2:
-                s *= 2
+            elif not (m.kind == 'up' and m.cout <= 3):
+                s *= m.rate
         self.n_sym = tot * B
         self.sym_all, self.idx_all = self.new(self.n_sym, torch.int32), self.new(self.n_sym, torch.uint8)
         self.sym_host = torch.empty(self.n_sym, dtype=torch.int32).pin_memory()
@@ -241,9 +288,19 @@ class _QresPlan(Plan):
                     self.cnx(p, m, x.data_ptr(), t.data_ptr(), h, w)
                     feats[h] = x
                     h, w = h // 2, w // 2
-                    nx = self.new(B * h * w * m.out_ch)
-                    self.gemm(A0=t.data_ptr(), K0=m.dim, M=B * h * w, N=m.out_ch, K=4 * m.dim, Wt=pk.p(p + '.downsapmle.w'),
-                              bias=pk.p(p + '.downsapmle.b'), out=nx.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w, label=p + '.down')
+                    if m.down_rate == 4:
+                        s2d = self.buf('s2d', B * h * w * 4 * m.dim)
+                        self.gemm(A0=t.data_ptr(), K0=m.dim, M=B * h * w, N=4 * m.dim, K=4 * m.dim, Wt=pk.p(p + '.s2d.w'),
+                                  bias=pk.p(p + '.s2d.b'), out=s2d.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w, exact=True,
+                                  label=p + '.space_to_depth')
+                        h, w = h // 2, w // 2
+                        nx = self.new(B * h * w * m.out_ch)
+                        self.gemm(A0=s2d.data_ptr(), K0=4 * m.dim, M=B * h * w, N=m.out_ch, K=16 * m.dim, Wt=pk.p(p + '.downsapmle.w'),
+                                  bias=pk.p(p + '.downsapmle.b'), out=nx.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w, label=p + '.down4')
+                    else:
+                        nx = self.new(B * h * w * m.out_ch)
+                        self.gemm(A0=t.data_ptr(), K0=m.dim, M=B * h * w, N=m.out_ch, K=4 * m.dim, Wt=pk.p(p + '.downsapmle.w'),
+                                  bias=pk.p(p + '.downsapmle.b'), out=nx.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w, label=p + '.down')
                     x = nx
             feats[h] = x
         # top-down path
@@ -254,6 +311,19 @@ class _QresPlan(Plan):
         self.out = None
         for i, m in enumerate(model.decoder.dec_blocks):
             p = f'decoder.dec_blocks.{i}'
+            if m.kind == 'deconv':
+                nf = self.new(B * h * w * 4 * m.cout)
+                self.gemm(A0=f.data_ptr(), K0=m.cin, M=B * h * w, N=4 * m.cout, K=9 * m.cin, Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'),
+                          out=nf.data_ptr(), a_mode=_native.A_CONV3, store=_native.ST_SHUFFLE, r=2, H=h, W=w, label=p + '.deconv')
+                f, h, w = nf, h * 2, w * 2
+                continue
+            if m.kind == 'nearest':
+                C = m.channels
+                nf = self.new(B * h * w * m.rate ** 2 * C)
+                self.gemm(A0=f.data_ptr(), K0=C, M=B * h * w, N=m.rate ** 2 * C, Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'), out=nf.data_ptr(),
+                          store=_native.ST_SHUFFLE, r=m.rate, H=h, W=w, exact=True, label=p + '.nearest')
+                f, h, w = nf, h * m.rate, w * m.rate
+                continue
             if m.kind == 'up':
                 nf = self.new(B * h * w * m.rate ** 2 * m.cout)
                 final = m.cout <= 3
@@ -282,12 +352,13 @@ class _QresPlan(Plan):
             else:
                 self.cuts.append(len(self.ops))
                 self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z, zp), p + '.dequantize')
-            v = self.buf('zproj_h', M * (hid // 2))
+            hp = (hid // 2 + 3) // 4 * 4
+            v = self.buf('zproj_h', M * hp)
             conv3 = m.k == 3
-            self.gemm(A0=zhat.data_ptr(), K0=zp, M=M, N=hid // 2, K=(9 * zp if conv3 else zp), Wt=pk.p(p + '.z_proj.0.w'),
+            self.gemm(A0=zhat.data_ptr(), K0=zp, M=M, N=hp, K=(9 * zp if conv3 else zp), Wt=pk.p(p + '.z_proj.0.w'),
                       bias=pk.p(p + '.z_proj.0.b'), out=v.data_ptr(), a_mode=_native.A_CONV3 if conv3 else _native.A_PLAIN, H=h, W=w,
                       epi=_native.EPI_BIAS_GELU, label=p + '.z_proj.0')
-            self.gemm(A0=v.data_ptr(), K0=hid // 2, M=M, N=m.width, Wt=pk.p(p + '.z_proj.2.w'), bias=pk.p(p + '.z_proj.2.b'),
+            self.gemm(A0=v.data_ptr(), K0=hp, M=M, N=m.width, Wt=pk.p(p + '.z_proj.2.w'), bias=pk.p(p + '.z_proj.2.b'),
                       res=f.data_ptr(), ldres=m.width, out=f.data_ptr(), epi=_native.EPI_RES, label=p + '.z_proj.2')
             self.cnx(p + '.resnet_end', m.resnet_end, f.data_ptr(), f.data_ptr(), h, w)
         self.lossless = isinstance(model.out_net, GaussianNLLOutParams)
@@ -357,6 +428,12 @@ class HierarchicalVAE(CodecBase):
         self.decoder = _Holder()
         self.decoder.dec_blocks = nn.ModuleList(config.pop('dec_blocks'))
         width = self.decoder.dec_blocks[0].width
+        cur = width
+        for b in self.decoder.dec_blocks:                     # nn.Upsample has no channel count of its own
+            if b.kind == 'nearest':
+                b.channels = cur
+            elif b.kind in ('up', 'deconv'):
+                cur = b.cout
         self.decoder.bias = nn.Parameter(torch.zeros(1, width, 1, 1))
         n_res = len([b for b in self.decoder.dec_blocks if hasattr(b, 'residual_scaling')])
         for b in self.decoder.dec_blocks:                     # TopDownDecoder._init_weights (:373-377)

@@ -38,6 +38,21 @@ def qres34m_arch():
     return dict(enc=enc, dec=dec, im_shift=-0.4546259594901961, im_scale=3.67572653978347, max_stride=64)
 
 
+def qres17m_arch():
+    """zoo.py:121-166."""
+    ch = 72
+    enc = [('down', 3, ch * 2, 4)]
+    enc += [('cnx', ch * 2, 7)] * 6 + [('cnxdown', ch * 2, ch * 4, 7)]
+    enc += [('cnx', ch * 4, 5)] * 6 + [('cnxdown', ch * 4, ch * 4, 7)]
+    enc += [('cnx', ch * 4, 3)] * 4 + [('cnxdown', ch * 4, ch * 4, 7, 4)]
+    enc += [('cnx', ch * 4, 1)] * 2
+    dec = [('qlb', ch * 4, 16, 1)] + [('nearest', 4)]
+    dec += [('qlb', ch * 4, 8, 3)] * 2 + [('deconv', ch * 4, ch * 4, 3)]
+    dec += [('qlb', ch * 4, 6, 5)] * 4 + [('deconv', ch * 4, ch * 2, 5)]
+    dec += [('qlb', ch * 2, 4, 7)] * 5 + [('up', ch * 2, 3, 4)]
+    return dict(enc=enc, dec=dec, im_shift=-0.4356, im_scale=3.397893306150187, max_stride=64)
+
+
 def qres34m_lossless_arch():
     """zoo.py:63-118: the qres34m backbone without its last patch_upsample, plus GaussianNLLOutputNet."""
     a = qres34m_arch()
@@ -69,11 +84,16 @@ def qres_param_shapes(arch):
         elif b[0] == 'cnx':
             out += _cnx_shapes(p, b[1], b[2])
         else:
-            out += _cnx_shapes(p, b[1], b[3]) + [(f'{p}.downsapmle.weight', (b[2], b[1], 2, 2)), (f'{p}.downsapmle.bias', (b[2],))]
+            r = b[4] if len(b) > 4 else 2
+            out += _cnx_shapes(p, b[1], b[3]) + [(f'{p}.downsapmle.weight', (b[2], b[1], r, r)), (f'{p}.downsapmle.bias', (b[2],))]
     for i, b in enumerate(arch['dec']):
         p = f'decoder.dec_blocks.{i}'
         if b[0] == 'up':
             out += [(f'{p}.0.weight', (b[2] * b[3] ** 2, b[1], 1, 1)), (f'{p}.0.bias', (b[2] * b[3] ** 2,))]
+        elif b[0] == 'deconv':
+            out += [(f'{p}.weight', (b[1], b[2], b[3], b[3])), (f'{p}.bias', (b[2],))]
+        elif b[0] == 'nearest':
+            pass
         else:
             _, w, z, k = b
             hid, k3 = int(w * 0.25), k >= 3
@@ -150,9 +170,19 @@ class QresOracle:
             elif b[0] == 'cnx':
                 x = my_cnx(self.sd, p, x)
             else:
-                x = conv(self.sd, f'{p}.downsapmle', my_cnx(self.sd, p, x), stride=2)      # model.py:184-192
+                x = conv(self.sd, f'{p}.downsapmle', my_cnx(self.sd, p, x), stride=(b[4] if len(b) > 4 else 2))      # model.py:184-192
             feats[int(x.shape[2])] = x
         return feats
+
+    def dec_other(self, p, b, feature):
+        if b[0] == 'up':                                                                   # common.py:33-38
+            return F.pixel_shuffle(conv(self.sd, f'{p}.0', feature), b[3])
+        if b[0] == 'deconv':                                                               # common.py:40-45
+            k = b[3]
+            return F.conv_transpose2d(feature, self.sd[f'{p}.weight'], self.sd[f'{p}.bias'], stride=2, padding=k // 2, output_padding=1)
+        if b[0] == 'nearest':                                                              # nn.Upsample(scale_factor=4)
+            return F.interpolate(feature, scale_factor=b[1], mode='nearest')
+        raise ValueError(b)
 
     def transform_prior(self, p, feature):                                                 # model.py:245-255
         feature = my_cnx(self.sd, f'{p}.resnet_front', feature)
@@ -187,7 +217,7 @@ class QresOracle:
                 feature = feature + self.z_proj(p, zhat)
                 feature = my_cnx(self.sd, f'{p}.resnet_end', feature)
             else:
-                feature = F.pixel_shuffle(conv(self.sd, f'{p}.0', feature), b[3])
+                feature = self.dec_other(p, b, feature)
         return dict(enc_features=feats, blocks=blocks, smallest=tuple(feats[min_res].shape), feature=feature)
 
     def _prepare_codec(self, feature, x=None):                                             # model.py:69-80
@@ -231,7 +261,7 @@ class QresOracle:
                 feature = feature + self.z_proj(p, zhat)
                 feature = my_cnx(self.sd, f'{p}.resnet_end', feature)
             else:
-                feature = F.pixel_shuffle(conv(self.sd, f'{p}.0', feature), b[3])
+                feature = self.dec_other(p, b, feature)
         assert si == len(obj) - 1
         if final is not None:                                                              # :88-94
             pm, plogv, _ = self._prepare_codec(feature)

@@ -210,7 +210,7 @@ def golden_progressive(model, h, w, lmb, tag, img_seed=0):
 
 
 @torch.no_grad()
-def golden_qres(model, h, w, tag, img_seed=0):
+def golden_qres(model, h, w, tag, img_seed=0, model_name='qres34m'):
     """qres34m (qresvae/model.py:649-725): per-block indexes/symbols/strings, reconstruction, pickle container size."""
     import pickle
     im, _ = image_tensor(h, w, img_seed)
@@ -249,10 +249,10 @@ def golden_qres(model, h, w, tag, img_seed=0):
     out['pickle_bytes'] = np.array(len(pickle.dumps(obj + [(h, w)])))
     xhat = model.decompress(obj)
     out['xhat'] = npf(xhat)
-    print('qres34m', tag, 'payload bytes', sum(len(r['string']) for r in recs), 'pickle', int(out['pickle_bytes']),
+    print(model_name, tag, 'payload bytes', sum(len(r['string']) for r in recs), 'pickle', int(out['pickle_bytes']),
           'sym range', [(int(r['symbols'].min()), int(r['symbols'].max())) for r in recs][:6],
           'idx range', [(int(r['indexes'].min()), int(r['indexes'].max())) for r in recs][:6])
-    np.savez_compressed(os.path.join(HERE, f'qres34m_{tag}.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, f'{model_name}_{tag}.npz'), **out)
 
 
 @torch.no_grad()
@@ -316,6 +316,14 @@ def main_qres():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'qres':
         return main_qres()
+    if len(sys.argv) > 1 and sys.argv[1] == 'qres17m':
+        model = lvae.get_model('qres17m')
+        load_seeded(model, 0)
+        model.eval()
+        model.compress_mode()
+        with open(os.path.join(HERE, 'qres17m_state_keys.json'), 'w') as f:
+            json.dump({k: list(v.shape) for k, v in model.state_dict().items() if 'discrete_gaussian' not in k}, f)
+        return golden_qres(model, 64, 128, '64x128', model_name='qres17m')
     if len(sys.argv) > 1 and sys.argv[1] == 'lossless':
         model = lvae.get_model('qres34m_lossless')
         load_seeded(model, 0)

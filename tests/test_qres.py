@@ -215,3 +215,78 @@ def test_lossless_hip_matches_reference_and_is_lossless(golden_dir, lossless_pro
     assert objs[1] == m.compress(ims[1:2])
     xb = m.decompress_batch(objs)
     assert torch.equal(torch.round(xb * 255.0), torch.round(ims * 255.0))
+
+
+# ----------------------------------------------------------------------------------- qres17m
+@pytest.fixture(scope='module')
+def q17_sd():
+    return seeded_init.seeded_state_dict(qres_oracle.qres_param_shapes(qres_oracle.qres17m_arch()), seed=0)
+
+
+def test_qres17m_inventory(q17_sd, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, 'qres17m_state_keys.json')))
+    assert {k: list(v.shape) for k, v in q17_sd.items()} == ref
+    import lvae
+    m = lvae.get_model('qres17m')
+    assert {k: list(v.shape) for k, v in m.state_dict().items() if 'discrete_gaussian' not in k} == ref
+    assert sum(v.size for v in q17_sd.values()) == 16678842
+
+
+def test_qres17m_oracle_matches_reference(golden_dir, q17_sd):
+    """4x4/s4 patch down-sampling, nearest x4 Upsample and the two stride-2 transposed convs (zoo.py:121-166)."""
+    g = np.load(os.path.join(golden_dir, 'qres17m_64x128.npz'))
+    h, w = g['hw'].tolist()
+    o = qres_oracle.QresOracle(q17_sd, arch=qres_oracle.qres17m_arch())
+    o.compress_mode()
+    im = _img(h, w, int(g['img_seed']))
+    tr = o.encode_trace(im, code=True)
+    assert tuple(g['smallest'].tolist()) == tr['smallest'] and len(tr['blocks']) == 12
+    n = flips = 0
+    for bi, blk in enumerate(tr['blocks']):
+        n += blk['symbols'].numel()
+        flips += int((blk['symbols'].numpy() != g[f'b{bi}.symbols']).sum()) + int((blk['indexes'].numpy() != g[f'b{bi}.indexes']).sum())
+        if flips == 0:
+            assert blk['strings'][0] == g[f'b{bi}.string'].tobytes()
+    assert flips <= FLIP_BUDGET * n
+    obj = o.compress(im)
+    xhat = o.decompress(obj)
+    np.testing.assert_allclose(xhat.numpy(), g['xhat'], rtol=0, atol=1e-4 if flips == 0 else 5e-2)
+
+
+@pytest.fixture(scope='module')
+def q17_product(q17_sd):
+    import lvae
+    m = lvae.get_model('qres17m')
+    full = m.state_dict()
+    for k, v in q17_sd.items():
+        full[k] = torch.from_numpy(v)
+    m.load_state_dict(full)
+    m.compress_mode()
+    return m.to('cuda:0').eval()
+
+
+@pytest.mark.gpu
+def test_qres17m_hip_matches_reference(golden_dir, q17_product):
+    m = q17_product
+    g = np.load(os.path.join(golden_dir, 'qres17m_64x128.npz'))
+    h, w = g['hw'].tolist()
+    im = _img(h, w, int(g['img_seed'])).cuda()
+    tr = m.encode_trace(im)
+    n = flips = 0
+    for bi, blk in enumerate(tr):
+        n += blk['symbols'].size
+        flips += int((blk['symbols'].reshape(-1) != g[f'b{bi}.symbols'].reshape(-1)).sum())
+        flips += int((blk['indexes'].reshape(-1) != g[f'b{bi}.indexes'].reshape(-1)).sum())
+    print(f'qres17m: {flips} flips of {n}')
+    assert len(tr) == 12 and flips <= FLIP_BUDGET * n
+    obj = m.compress(im)
+    assert tuple(obj[-1]) == tuple(g['smallest'].tolist()) and len(obj) == 13
+    xhat = m.decompress(obj)
+    if flips == 0:
+        for bi in range(12):
+            assert obj[bi][0] == g[f'b{bi}.string'].tobytes()
+        assert float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max()) <= 1e-4
+    ims = torch.cat([_img(128, 64, s) for s in (1, 2, 3)], 0).cuda()
+    objs = m.compress_batch(ims)
+    assert objs[2] == m.compress(ims[2:3])
+    assert torch.equal(m.decompress_batch(objs)[1:2], m.decompress(objs[1]))
