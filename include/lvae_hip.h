@@ -125,6 +125,12 @@ typedef struct {
     int  cfg;                             /* tile configuration: 0 = library heuristic, k>0 = candidate k-1 of
                                              lvae_gemm_num_configs() (results are bit-identical for every choice;
                                              the Python host autotunes this per shape at plan-build time) */
+    int  ksplit;                          /* split-K: S > 1 cuts K into S equal slices (K % (32*S) == 0) computed by S x tiles
+                                             workgroups into `ws`, then reduced IN SLICE ORDER and passed through the epilogue by a
+                                             second kernel -- deterministic; for the few-tile, long-K layers (stride 32/64 MLPs, 3x3
+                                             heads).  Row-major store only, N % 4 == 0.  The host must choose S independently of
+                                             the batch size (per-image rows), so that batched and single-image calls agree */
+    float* ws;                            /* split-K workspace, S*M*N floats (unused when ksplit <= 1) */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */

@@ -177,4 +177,17 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
     }
 }
 
+// Every GEMM kernel ends here.  gridDim.y = number of K slices: with split-K the raw partial sums of slice blockIdx.y go to its
+// workspace plane (row-major, no bias / activation / residual); splitk_reduce_kernel (gemm_f32.hip) finishes the job.
+template <class C>
+__device__ __forceinline__ void gemm_finish(const lvae_gemm_desc& d, f32x16 (&acc)[C::TM][C::TN], int m0, int n0, int wave_m,
+                                            int wave_n, int li, int lh) {
+    lvae_gemm_desc p = d;
+    if (gridDim.y > 1) {
+        p.out = d.ws + (long)blockIdx.y * d.M * d.N;
+        p.ldo = d.N; p.bias = nullptr; p.epi = LVAE_EPI_BIAS; p.store = LVAE_ST_ROWMAJOR; p.res = nullptr; p.ldres = 0;
+    }
+    gemm_epilogue<C>(p, acc, m0, n0, wave_m, wave_n, li, lh);
+}
+
 }  // namespace

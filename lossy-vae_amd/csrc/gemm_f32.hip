@@ -143,7 +143,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     f32x4 ra[C::NA], rb[C::NB];
-    const int nk = (d.K + BK - 1) / BK;
+    const int nk = ((d.K + BK - 1) / BK) / (int)gridDim.y, kt0 = (int)blockIdx.y * nk;      // split-K: this slice's k-tiles
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     unsigned okmask = 0;      // bit i: ra[i] is real data; bit 16: the W chunk is real data (k < K)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
     // right after the barrier saturated the CU's vector-memory issue (in-kernel timeline: 2-5k cycles with NO wave in
     // its MFMA phase, 15-25% of a k-tile); spread out, each load issues in the shadow of the preceding MFMAs.
     auto gload = [&](int kt, int part, int nparts) {
-        const int k = kt * BK + sk4 * 4;
+        const int k = (kt0 + kt) * BK + sk4 * 4;
         if (part == 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < C::NA; ++i) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
 #else
 #define TRACE_END() do {} while (0)
 #endif
-    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
     TRACE_END();
 }
 
@@ -308,9 +308,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_des
     f32x4 ra[NA];
     bf16x8 rb[NB];
     unsigned okmask = 0;
-    const int nk = (d.K + KT - 1) / KT;
+    const int nk = ((d.K + KT - 1) / KT) / (int)gridDim.y, kt0 = (int)blockIdx.y * nk;      // split-K: this slice's k-tiles
     auto gload = [&](int kt, int part, int nparts) {
-        const int k = kt * KT + ak4 * 4;
+        const int k = (kt0 + kt) * KT + ak4 * 4;
         if (part == 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_des
             ra[i] = load_a<AMODE>(d, ri[i], k, ok);
             okmask |= (ok ? 1u : 0u) << i;
         }
-        const int kw = kt * KT + wk8 * 8;
+        const int kw = (kt0 + kt) * KT + wk8 * 8;
         const bool wok = kw < d.K;
         const int kc = wok ? kw : d.K - 8;
         if (part == 0) okmask |= (wok ? 1u : 0u) << 16;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_des
             __syncthreads();
         }
     }
-    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 }
 
 // ---------------------------------------------------------------- fp32-accurate split variant ("bf16x3")
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(const lvae_gemm_desc 
     f32x4 ra[NA];
     bf16x8 rb[3][NB];
     unsigned okmask = 0;
-    const int nk = (d.K + KT - 1) / KT;
+    const int nk = ((d.K + KT - 1) / KT) / (int)gridDim.y, kt0 = (int)blockIdx.y * nk;      // split-K: this slice's k-tiles
     auto gload = [&](int kt) {
-        const int k = kt * KT + ak4 * 4;
+        const int k = (kt0 + kt) * KT + ak4 * 4;
         okmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(const lvae_gemm_desc 
             ra[i] = load_a<AMODE>(d, ri[i], k, ok);
             okmask |= (ok ? 1u : 0u) << i;
         }
-        const int kw = kt * KT + wk8 * 8;
+        const int kw = (kt0 + kt) * KT + wk8 * 8;
         const bool wok = kw < d.K;
         const int kc = wok ? kw : d.K - 8;
         okmask |= (wok ? 1u : 0u) << 16;
@@ -523,8 +523,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(const lvae_gemm_desc 
             __syncthreads();
         }
     }
-    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 }
+
+inline int ksp(const lvae_gemm_desc* d) { return d->ksplit > 1 ? d->ksplit : 1; }
 
 template <class C, int AMODE>
 int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
@@ -547,17 +549,17 @@ int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
     }
     if constexpr (C::BK == 32) {
         if (d->prec == 1) {
-            hipLaunchKernelGGL((gemm_bf16_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
+            hipLaunchKernelGGL((gemm_bf16_kernel<C, AMODE>), dim3(n_tiles, ksp(d)), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
             return (int)hipGetLastError();
         }
         if (d->prec == 2) {
             constexpr int lds_x3 = (C::BM + C::BN) * 208;
             static_assert(lds_x3 <= 160 * 1024, "x3 LDS");
-            hipLaunchKernelGGL((gemm_x3_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), lds_x3, st, *d, tiles_n, n_tiles);
+            hipLaunchKernelGGL((gemm_x3_kernel<C, AMODE>), dim3(n_tiles, ksp(d)), dim3(C::NT), lds_x3, st, *d, tiles_n, n_tiles);
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<C, AMODE>), dim3(n_tiles), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
+    hipLaunchKernelGGL((gemm_kernel<C, AMODE>), dim3(n_tiles, ksp(d)), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -599,7 +601,7 @@ inline double tile_cost(int M, int N, int K, int BM, int BN, int wg_per_cu, doub
 
 template <int AMODE>
 int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
-    const int N = d->N, M = d->M, K = d->K;
+    const int N = d->N, M = d->M * ksp(d), K = d->K / ksp(d);      // split-K: S x the tiles, 1/S the depth
     if (d->cfg <= 0 && g_force_cfg < 0) {
         if (N <= 32 || N == 96) return launch_cfg<CfgC, AMODE>(d, st);
         if (N <= 64) return launch_cfg<CfgB, AMODE>(d, st);
@@ -625,6 +627,8 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     if (d->prec != 0 && id == 10) id = 2;
     if (d->prec != 0 && id == 11) id = 1;
     if (d->prec == 2 && id == 7) id = 3;          // 128x256 x3 instance spills; 256x256 covers the same shapes
+    if (ksp(d) > 1 && id == 10) id = 2;           // split-K slices are counted in 32-deep k-tiles
+    if (ksp(d) > 1 && id == 11) id = 1;
     switch (id) {
         case 0: return launch_cfg<CfgA, AMODE>(d, st);
         case 1: return launch_cfg<CfgB, AMODE>(d, st);
@@ -641,11 +645,42 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     }
 }
 
+// split-K second pass: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias), 4 columns per thread, 16-B accesses
+__global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = d.N >> 2;
+    if (e >= (long)d.M * n4) return;
+    const long m = e / n4;
+    const int c = (int)(e - m * n4) * 4;
+    const long plane = (long)d.M * d.N;
+    const float* w = d.ws + m * d.N + c;
+    f32x4 v = *(const f32x4*)w;
+    for (int s = 1; s < S; ++s) {
+        const f32x4 p = *(const f32x4*)(w + s * plane);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    if (d.bias) { const f32x4 b = *(const f32x4*)(d.bias + c); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (d.epi == LVAE_EPI_BIAS_GELU) {
+        float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        gelu_erf2(a0, a1); gelu_erf2(a2, a3);
+        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+    } else if (d.epi == LVAE_EPI_GAMMA_RES) {
+        const f32x4 g = *(const f32x4*)(d.gamma + c), r = *(const f32x4*)(d.res + m * d.ldres + c);
+        v[0] = r[0] + g[0] * v[0]; v[1] = r[1] + g[1] * v[1]; v[2] = r[2] + g[2] * v[2]; v[3] = r[3] + g[3] * v[3];
+    } else if (d.epi == LVAE_EPI_RES) {
+        const f32x4 r = *(const f32x4*)(d.res + m * d.ldres + c);
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    *(f32x4*)(d.out + m * d.ldo + c) = v;
+}
+
 }  // namespace
 
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
+static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn);
+static int gemm_dispatch(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) { return gemm_dispatch_impl(d, st, x3v2, x3v2_tn); }
 
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     static bool env_read = false;
@@ -664,6 +699,21 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
     if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;
     hipStream_t st = (hipStream_t)stream;
+    const int S = ksp(d);
+    if (S > 1) {
+        if (!d->ws || d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S) ||
+            (d->prec == 1 && d->K % (64 * S)))
+            return -22;
+        const int rc = gemm_dispatch(d, st, x3v2, x3v2_tn);
+        if (rc) return rc;
+        const long n = (long)d->M * (d->N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d, S);
+        return (int)hipGetLastError();
+    }
+    return gemm_dispatch(d, st, x3v2, x3v2_tn);
+}
+
+static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) {
     if (d->prec == 2 && x3v2 && d->cfg == 0 && d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) {   // cfg -1: legacy kernel
         int rc = 0;
         if (lvae_gemm_x3v2_try(d, st, x3v2_tn, &rc)) return rc;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3w8_kernel(const lvae_gemm_desc 
         }
         __syncthreads();
     }
-    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 }
 
 template <bool AGELU>
@@ -239,13 +239,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
     const int li = lane & 31, lh = lane >> 5;
     auto perm = [](int q) { return (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1); };        // 0,2,4,6,1,3,5,7
 
+    // split-K (gridDim.y slices): this workgroup covers k16 stages [q0, q0 + nq); the slice offset goes into the buffer bases
+    const int nq = d.K / 16 / (int)gridDim.y, q0 = (int)blockIdx.y * nq;
     const int rows_a = (d.M - m0) < C::BM ? (d.M - m0) : C::BM;
-    const __amdgpu_buffer_rsrc_t rsA =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(d.A0 + (long)m0 * d.lda0), 0, rows_a * d.lda0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(d.A0 + (long)m0 * d.lda0 + q0 * 16), 0,
+                                                                         rows_a * d.lda0 * 4 - q0 * 64, 0x00020000);
     const int rows_w = (d.N - n0) < C::BN ? (d.N - n0) : C::BN;
     const long wrow_b = (long)6 * d.K;                            // bytes per W row in the k16-interleaved copy
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(d.Wt16 + (long)3 * d.N * d.ldw + (long)n0 * 3 * d.K), 0, (int)(rows_w * wrow_b), 0x00020000);
+        (void*)(d.Wt16 + (long)3 * d.N * d.ldw + (long)n0 * 3 * d.K + q0 * 48), 0, (int)(rows_w * wrow_b) - q0 * 96, 0x00020000);
     int a_voff[2], a_st[2], w_voff[NW], w_st[NW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -272,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
 
     u32x4 ra[2][2], rb[2][NW];        // [stage parity][chunk]
     u32x2 sa[3];
-    const int nq = d.K / 16;
     auto load_a = [&](int par, int j, int q) { ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_voff[j], q * 64, 0); };
     auto load_w = [&](int par, int j, int q) { rb[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_voff[j], q * 96, 0); };
     auto split_half = [&](int par, int j, int h) {
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
 #ifdef LVAE_X3V2_TRACE
     if (tracing) lvae_trace_buf[121] = __builtin_readcyclecounter();
 #endif
-    gemm_epilogue<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
 #ifdef LVAE_X3V2_TRACE
     if (tracing) lvae_trace_buf[122] = __builtin_readcyclecounter();
 #endif
@@ -403,7 +404,8 @@ int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
         attr_set = true;
     }
     const int tiles_m = (d->M + 127) / 128, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU>), dim3(n_tiles), dim3(256), LDS + g_x3v2_lds_pad, st, *d, tiles_n, n_tiles);
+    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU>), dim3(n_tiles, d->ksplit > 1 ? d->ksplit : 1), dim3(256), LDS + g_x3v2_lds_pad, st, *d,
+                       tiles_n, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -415,14 +417,17 @@ int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
     if (d->prec != 2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || (d->K & 31) || (d->lda0 & 3) || d->ldw != d->K) return 0;
     if ((long)256 * d->lda0 * 4 > 0x7fffffffL || (long)6 * d->N * d->K > 0x7fffffffL) return 0;
-    const int M = d->M, N = d->N, K = d->K;
+    const int S = d->ksplit > 1 ? d->ksplit : 1;
+    if (S > 1 && (d->K % (32 * S))) return 0;
+    const int M = d->M, N = d->N, K = d->K / S;
     int sel = force;
+    if (S > 1 && sel == 8) sel = 0;
     if (sel <= 0) {
         // k16 kernels: rounds of 128 x 64c tiles over 2 x 256 workgroup slots x per-tile work / measured relative efficiency
         double best = 1e300;
         const double eff[4] = {0, 0.70, 1.00, 1.03};
         for (int c = 1; c <= 3; ++c) {
-            const long tiles = (long)((M + 127) / 128) * ((N + 64 * c - 1) / (64 * c));
+            const long tiles = (long)((M + 127) / 128) * ((N + 64 * c - 1) / (64 * c)) * S;
             const long rounds = (tiles + 511) / 512;
             const double cost = rounds * (128.0 * 64 * c) * (K + 96.0) / eff[c];
             if (cost < best) { best = cost; sel = c; }
@@ -430,7 +435,7 @@ int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* 
         // 8-wave 256 x 128 tiles, one per CU: better inside a tile (70 % vs 55 % MFMA-busy) but whole rounds of 256 tiles; taken when
         // the problem is one well-filled round and long enough to amortise the un-overlapped prologue / epilogue
         const long t8 = (long)((M + 255) / 256) * ((N + 127) / 128);
-        if (t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
+        if (S == 1 && t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
     }
     if (sel == 8) {
         *rc = d->a_gelu ? launch_w8<true>(d, st) : launch_w8<false>(d, st);

@@ -55,6 +55,32 @@ def autotune_gemm(lib, d, stream_ptr, device):
     return best
 
 
+KSPLIT = os.environ.get('LVAE_KSPLIT', '1') != '0'
+
+
+def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
+    """Number of K slices for a GEMM whose PER-IMAGE row count is m1 (so the choice does not depend on the batch size: batched
+    and single-image calls, and the encoder and decoder of one image size, use the same summation order).  Split-K is for the
+    few-tile, long-K layers only (stride-32/64 MLPs, the 3x3 posterior heads): there a workgroup's K loop, not the MFMA rate, sets
+    the launch time (~1500 cycles per 16-deep stage whatever the tile)."""
+    if not KSPLIT or store != _native.ST_ROWMAJOR or (N & 3) or (ldo & 3) or (ldres & 3) or K % 32:
+        return 1
+    nk = K // 32
+    if prec == 1:
+        if K % 64:
+            return 1
+        nk = K // 64
+    tiles1 = ((m1 + 127) // 128) * ((N + 63) // 64)
+    if tiles1 > 32:
+        return 1
+    limit = min(nk // 4, 256 // tiles1)              # >= 4 k-tiles (128 deep) per slice; about one slice-tile per CU
+    best = 1
+    for s in range(2, max(2, limit) + 1):
+        if s <= limit and nk % s == 0:
+            best = s
+    return best
+
+
 class Plan:
     autotune = os.environ.get('LVAE_AUTOTUNE', '0') == '1'    # opt-in: in-situ gains were within noise (DESIGN.md 5)
 
@@ -94,7 +120,7 @@ class Plan:
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, label='gemm'):
         if K is None:
             K = K0 + K1
         if Wt16 is None and self.w16 is not None:
@@ -114,6 +140,10 @@ class Plan:
         # 0/1 weights: nearest upsampling, space-to-depth -- x*1 + 0*... must reproduce x bit for bit)
         d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
         d.Wt16 = Wt16 if d.prec else None
+        if ksplit is None:
+            ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
+        if ksplit > 1:
+            d.ksplit, d.ws = ksplit, self.buf('splitk_ws', ksplit * M * N).data_ptr()
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             d.cfg = autotune_gemm(self.lib, d, sp, self.device)

@@ -319,3 +319,52 @@ def test_quantize_padded_rows_and_gemm_a_gelu(L):
     _gemm(L, A0=x.permute(0, 2, 3, 1).contiguous(), K0=C, H=H, W=W, Wt=w.permute(0, 2, 3, 1).reshape(C, -1).contiguous(), ldw=9 * C,
           bias=bb, out=o2, ldo=C, M=Bc * H * W, N=C, K=9 * C, a_mode=2, epi=1)
     assert (o2.view(Bc, H, W, C).double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('prec', [0, 2])
+@pytest.mark.parametrize('M,N,K,S,epi,a_mode', [(384, 512, 1024, 8, 2, 0), (96, 512, 2048, 8, 1, 0), (768, 1024, 512, 4, 1, 0),
+                                                (300, 32, 4608, 16, 0, 2), (130, 64, 1152, 9, 3, 0)])
+def test_gemm_split_k(M, N, K, S, epi, a_mode, prec):
+    """Split-K (ksplit = S): fp32-class accuracy against an fp64 reference, deterministic, and -- the property the host relies on --
+    independent of M for a fixed S: the rows of a batch are bit-identical to the rows of a smaller call."""
+    import ctypes
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(M + N + K + S)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if a_mode == 2:                      # 3x3 gather over an NHWC map: M = B*H*W pixels, K = 9*Cin
+        Hh, Ww, Cin = 10, M // 10, K // 9
+        A = torch.randn(M, Cin, generator=g).cuda()
+    else:
+        Hh = Ww = 0
+        Cin = K
+        A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    W3 = pack_bf16x3(Wt)
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+
+    def run(m_rows, ksplit):
+        out = torch.full((m_rows, N), float('nan'), device='cuda')
+        ws = torch.empty(max(1, ksplit) * m_rows * N, device='cuda')
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = A.data_ptr(), Cin, Cin, Wt.data_ptr(), W3.data_ptr(), K
+        d.bias, d.gamma, d.res, d.ldres, d.out, d.ldo = bias.data_ptr(), gamma.data_ptr(), res.data_ptr(), N, out.data_ptr(), N
+        d.M, d.N, d.K, d.epi, d.prec, d.a_mode, d.H, d.W = m_rows, N, K, epi, prec, a_mode, Hh, Ww
+        d.ksplit, d.ws = ksplit, ws.data_ptr()
+        assert L.lvae_gemm_f32(ctypes.byref(d), st) == 0
+        torch.cuda.synchronize()
+        return out
+
+    o1, oS, oS2 = run(M, 1), run(M, S), run(M, S)
+    assert torch.equal(oS, oS2)
+    if a_mode == 0:
+        ref = A.double() @ Wt.double().t() + bias.double()
+        ref = {0: ref, 1: torch.nn.functional.gelu(ref), 2: res.double() + gamma.double() * ref, 3: res.double() + ref}[epi]
+        e1, eS = float((o1.double() - ref).abs().max()), float((oS.double() - ref).abs().max())
+        assert eS <= 2 * e1 + 2e-6, (e1, eS)
+        half = (M // 2) // 2 * 2
+        assert torch.equal(run(half, S), oS[:half])          # M-independence (rows of a smaller call)
+    else:
+        assert float((oS - o1).abs().max()) <= 2e-5 * max(1.0, float(o1.abs().max()))
