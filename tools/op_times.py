@@ -50,7 +50,10 @@ def main():
                     k = (key[0], 'gemm', d.M, d.N, d.K, f'amode{d.a_mode} epi{d.epi} st{d.store}')
                     fl = 2.0 * d.M * d.N * d.K
                 else:
-                    k = (key[0], name.replace('lvae_', ''), label.split('.')[-1], 0, 0, '')
+                    if 'dwconv' in name:          # args: x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k
+                        k = (key[0], 'dwconv_ln', f'{a[9]}x{a[10]}', int(a[11]), int(a[12]), '(H x W, C, k)')
+                    else:
+                        k = (key[0], name.replace('lvae_', ''), label.split('.')[-1], 0, 0, '')
                 r = agg[k]
                 r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e3; r[2] += fl
     tot = sum(r[1] for r in agg.values()) / reps
