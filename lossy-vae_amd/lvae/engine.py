@@ -73,7 +73,7 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
     tiles1 = ((m1 + 127) // 128) * ((N + 63) // 64)
     if tiles1 > 32:
         return 1
-    limit = min(nk // 4, 256 // tiles1)              # >= 4 k-tiles (128 deep) per slice; about one slice-tile per CU
+    limit = min(nk // 4, int(os.environ.get("LVAE_KSPLIT_TILES", "256")) // tiles1)   # >= 4 k-tiles (128 deep) per slice
     best = 1
     for s in range(2, max(2, limit) + 1):
         if s <= limit and nk % s == 0:
