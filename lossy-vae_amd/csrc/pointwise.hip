@@ -154,6 +154,172 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
     }
 }
 
+// Tiled, software-pipelined form of the same operator for the large C = 128 / 192 maps (stride 4).  dwconv_ln_kernel re-reads every
+// input pixel k times per channel chunk from L2 (nothing survives in the 32 KB L1): ~27 of the 34.5 TB/s of L2 bandwidth at k = 7.
+// Here 512 threads (32 groups of 16 lanes x 4 pixels) own an 8 x 16 pixel tile; per channel chunk the tile and its (k-1) halo are
+// staged ONCE in LDS and the k x k window slides over LDS; all k*k*C weights sit in LDS too, so the compute phase issues no
+// vector-memory instruction and the global loads of the NEXT chunk (or of the next tile's first chunk: workgroups are persistent)
+// stay in flight in registers behind it (an in-order vmcnt wait on a weight load would otherwise drain them).
+// Channel -> lane ownership, tap order and the LayerNorm reduction order are dwconv_ln_kernel's: same bits, free choice per launch.
+template <int KS, int VPL>
+__global__ __launch_bounds__(512, 1) void dwconv_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                                const float* __restrict__ ln_b, const float* __restrict__ shift,
+                                                                const float* __restrict__ scale1p, float* __restrict__ y,
+                                                                int B, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int LPP = 16, TW = 4, GX = 4, GY = 8, TBW = GX * TW, TBH = GY, PGB = 32;
+    constexpr int C = 4 * VPL * LPP;
+    constexpr int P = (KS - 1) / 2, LW = TBW + KS - 1, LH = TBH + KS - 1, NPIX = LW * LH;
+    constexpr int NF = (NPIX + PGB - 1) / PGB;                       // staged float4 per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    f32x4* tile = (f32x4*)dw_lds;                                   // [NPIX][16]
+    f32x4* wl = tile + NPIX * LPP;                                  // [VPL][KS*KS][16]
+    const int tid = threadIdx.x, cl = tid % LPP, pg = tid / LPP;
+    const int gy = pg / GX, gx = pg % GX;
+    // contiguous range of tiles per workgroup (neighbouring tiles share halos in one XCD's L2: blockIdx % 8 is the XCD)
+    const int nb = gridDim.x, bq = nb / 8, br = nb % 8, xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    const int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + loc;
+    const int per = n_tiles / nb, rem = n_tiles % nb;
+    const int t_begin = bid * per + (bid < rem ? bid : rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
+
+    for (int e = tid; e < VPL * KS * KS * LPP; e += 512) {           // weights: wl[(v*KK + tap)*16 + lane] = wt[tap*C + 4*(lane + 16 v)]
+        const int lane = e % LPP, tap = (e / LPP) % (KS * KS), v = e / (LPP * KS * KS);
+        wl[e] = *(const f32x4*)(wt + (long)tap * C + 4 * (lane + v * LPP));
+    }
+    int lyx[NF];                                                     // halo-tile coordinates of this thread's staged pixels
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        const int pix = pg + PGB * n, ly = pix / LW;
+        lyx[n] = (pix < NPIX) ? ((ly << 8) | (pix - ly * LW)) : -1;
+    }
+    f32x4 st[NF];
+    unsigned inmask = 0;
+    auto prefetch = [&](int t, int v) {                              // global -> registers, branch-free (clamped address + mask)
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        const long b = t / (tiles_x * tiles_y);
+        const float* xb = x + b * (long)H * W * C + 4 * (cl + v * LPP);
+        const int h0 = ty * TBH - P, w0 = tx * TBW - P;
+        inmask = 0;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int hh = h0 + (lyx[n] >> 8), ww = w0 + (lyx[n] & 255);
+            const bool in = lyx[n] >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            inmask |= (in ? 1u : 0u) << n;
+            st[n] = *(const f32x4*)(xb + (in ? ((long)hh * W + ww) * C : 0));
+        }
+    };
+    auto commit = [&]() {                                            // registers -> LDS tile
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+            if (lyx[n] >= 0) tile[(pg + PGB * n) * LPP + cl] = ((inmask >> n) & 1u) ? st[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    if (t_begin < t_end) prefetch(t_begin, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        const long b = t / (tiles_x * tiles_y);
+        const int h0 = ty * TBH, w0 = tx * TBW;
+        f32x4 acc[VPL][TW];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            __syncthreads();                                         // previous chunk's readers are done (first pass: weights are in)
+            commit();
+            __syncthreads();
+            if (v + 1 < VPL) prefetch(t, v + 1);
+            else if (t + 1 < t_end) prefetch(t + 1, 0);
+            const f32x4 bv = *(const f32x4*)(bias + 4 * (cl + v * LPP));
+#pragma unroll
+            for (int q = 0; q < TW; ++q) acc[v][q] = bv;
+#pragma unroll 1
+            for (int i = 0; i < KS; ++i) {
+                const f32x4* row = tile + ((gy + i) * LW + gx * TW) * LPP + cl;
+                const f32x4* wrow = wl + (v * KS * KS + i * KS) * LPP + cl;
+                f32x4 xr[TW + KS - 1];
+#pragma unroll
+                for (int q = 0; q < TW + KS - 1; ++q) xr[q] = row[q * LPP];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const f32x4 wv = wrow[j * LPP];
+#pragma unroll
+                    for (int q = 0; q < TW; ++q) {
+                        acc[v][q][0] = fmaf(xr[q + j][0], wv[0], acc[v][q][0]);
+                        acc[v][q][1] = fmaf(xr[q + j][1], wv[1], acc[v][q][1]);
+                        acc[v][q][2] = fmaf(xr[q + j][2], wv[2], acc[v][q][2]);
+                        acc[v][q][3] = fmaf(xr[q + j][3], wv[3], acc[v][q][3]);
+                    }
+                }
+            }
+        }
+        const float inv_c = 1.0f / (float)C;
+        const int hh = h0 + gy;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) s += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * inv_c;
+            float sq = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = acc[v][q][e] - mean;
+                    acc[v][q][e] = dlt;
+                    sq = fmaf(dlt, dlt, sq);
+                }
+            }
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
+            const int ww = w0 + gx * TW + q;
+            if (ww < W && hh < H) {
+                float* yp = y + ((b * H + hh) * (long)W + ww) * C;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int c = 4 * (cl + v * LPP);
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][q][e] * rstd;
+                    if (ln_w) {
+                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
+                    }
+                    if (shift) {
+                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
+                    }
+                    *(f32x4*)(yp + c) = o4;
+                }
+            }
+        }
+    }
+}
+
+int g_dw_tile = -1;    // tuning hook (LVAE_DW_TILE): 0 = never, 1 = whenever an instance exists, -1 = heuristic
+
+template <int KS, int VPL>
+int launch_dwln_tile(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                     const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+    constexpr int NPIX = (16 + KS - 1) * (8 + KS - 1), LDS = (NPIX + VPL * KS * KS) * 256;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv_ln_tile_kernel<KS, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 7) / 8;
+    const long n_tiles = (long)B * tiles_x * tiles_y;
+    const int grid = n_tiles < 256 ? (int)n_tiles : 256;
+    hipLaunchKernelGGL((dwconv_ln_tile_kernel<KS, VPL>), dim3(grid), dim3(512), LDS, st, x, wt, bias, ln_w, ln_b, shift, scale1p, y,
+                       B, H, W, tiles_x, tiles_y, (int)n_tiles);
+    return (int)hipGetLastError();
+}
+
 int g_dw_th = 0;       // tuning hook (LVAE_DW_TH): 1 or 2 output rows per group; 0 = heuristic
 
 template <int KS, int VPL, int LPP, int TH>
@@ -176,6 +342,10 @@ int launch_dwln(const float* x, const float* wt, const float* bias, const float*
     // slower on the C >= 256 layers, where 200+ VGPRs halve the occupancy.  Same accumulation order => same bits either way.
     const long px = (long)B * H * W;
     constexpr int C = 4 * VPL * LPP;
+    if constexpr (KS >= 5 && LPP == 16 && VPL <= 3) {
+        if (g_dw_tile == 1 || (g_dw_tile < 0 && px >= 90000 && H >= 16 && W >= 32))      // >= ~3 tiles per CU; measured equal at 1.5
+            return launch_dwln_tile<KS, VPL>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    }
     int th = g_dw_th ? g_dw_th : ((KS == 7 && C <= 192 && VPL <= 3 && px >= 100000) ? 2 : 1);
     if (KS == 1 || VPL > 4) th = 1;          // VPL = 9 (C = 144, 288) has no registers for a second row
     if (th == 2) return launch_dwln_th<KS, VPL, LPP, (KS == 1 ? 1 : 2)>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -470,7 +640,11 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
     if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
     if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
     static bool env_read = false;
-    if (!env_read) { const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e); env_read = true; }
+    if (!env_read) {
+        const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e);
+        e = getenv("LVAE_DW_TILE"); if (e) g_dw_tile = atoi(e);
+        env_read = true;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (k) {
         case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);

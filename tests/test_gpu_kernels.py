@@ -370,17 +370,18 @@ def test_gemm_split_k(M, N, K, S, epi, a_mode, prec):
         assert float((oS - o1).abs().max()) <= 2e-5 * max(1.0, float(o1.abs().max()))
 
 
-@pytest.mark.parametrize('C,k,H,W,B', [(192, 7, 96, 160, 7), (128, 7, 61, 99, 18)])
-def test_dwconv_ln_two_row_variant_same_bits(L, C, k, H, W, B):
-    """Above 100 000 pixels per launch the k = 7, C <= 192 layers run the two-output-rows-per-group variant: a batch over the
-    threshold must give, image by image, the bits of single-image calls (one row per group) -- ragged sizes included."""
+@pytest.mark.parametrize('C,k,H,W,B', [(192, 7, 96, 160, 7), (128, 7, 61, 99, 18), (192, 5, 70, 130, 11), (128, 5, 64, 128, 12),
+                                       (128, 7, 17, 33, 170)])
+def test_dwconv_ln_large_map_variants_same_bits(L, C, k, H, W, B):
+    """Above 90 000 pixels per launch the k >= 5, C <= 192 layers run the LDS-tiled persistent kernel: a batch over the threshold
+    must give, image by image, the bits of single-image calls (register sliding-window kernel) -- ragged sizes included."""
     g = torch.Generator().manual_seed(C + k + H + W)
     x1 = torch.randn(3, H, W, C, generator=g).cuda()
     x = x1.repeat((B + 2) // 3, 1, 1, 1)[:B].contiguous()
     wp = (torch.randn(k * k, C, generator=g) / k).cuda()
     b = torch.randn(C, generator=g).cuda()
     shift, sc1 = torch.randn(C, generator=g).cuda(), (1 + 0.3 * torch.randn(C, generator=g)).cuda()
-    assert B * H * W >= 100000 > H * W
+    assert B * H * W >= 90000 > H * W
     out = torch.full((B, H, W, C), float('nan'), device='cuda')
     assert L.lvae_dwconv_ln_f32(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, shift.data_ptr(), sc1.data_ptr(), out.data_ptr(),
                                 B, H, W, C, k, _st()) == 0
