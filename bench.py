@@ -109,7 +109,7 @@ def cpu_baseline(sd, H, W, n_images=12, threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--height', type=int, default=512)

@@ -61,7 +61,7 @@ KSPLIT = os.environ.get('LVAE_KSPLIT', '1') != '0'
 def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
     """Number of K slices for a GEMM whose PER-IMAGE row count is m1 (so the choice does not depend on the batch size: batched
     and single-image calls, and the encoder and decoder of one image size, use the same summation order).  Split-K is for the
-    few-tile, long-K layers only (stride-32/64 MLPs, the 3x3 posterior heads): there a workgroup's K loop, not the MFMA rate, sets
+    few-tile, long-K layers only (stride-16..64 MLPs, the 3x3 posterior heads; <= 96 tiles per image): there a workgroup's K loop, not the MFMA rate, sets
     the launch time (~1500 cycles per 16-deep stage whatever the tile)."""
     if not KSPLIT or store != _native.ST_ROWMAJOR or (N & 3) or (ldo & 3) or (ldres & 3) or K % 32:
         return 1
@@ -71,7 +71,7 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
             return 1
         nk = K // 64
     tiles1 = ((m1 + 127) // 128) * ((N + 63) // 64)
-    if tiles1 > 32:
+    if tiles1 > int(os.environ.get("LVAE_KSPLIT_MAXT", "96")):
         return 1
     limit = min(nk // 4, int(os.environ.get("LVAE_KSPLIT_TILES", "256")) // tiles1)   # >= 4 k-tiles (128 deep) per slice
     best = 1

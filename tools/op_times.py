@@ -57,7 +57,10 @@ def main():
                 r = agg[k]
                 r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e3; r[2] += fl
     tot = sum(r[1] for r in agg.values()) / reps
-    print(f'total launch time per step (single stream, event-timed): {tot / 1e3:.2f} ms')
+    byplan = defaultdict(float)
+    for k, r in agg.items():
+        byplan[k[0]] += r[1] / reps
+    print(f'total launch time per step (single stream, event-timed): {tot / 1e3:.2f} ms  ' + ', '.join(f'{k}: {v / 1e3:.2f} ms' for k, v in byplan.items()))
     print(f'{"plan":5s} {"op":14s} {"M":>7s} {"N":>5s} {"K":>5s} {"flags":18s} {"calls":>5s} {"us/call":>8s} {"ms/step":>8s} {"pct":>5s} {"TF/s":>6s}')
     for k, r in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
         calls = r[0] // reps
