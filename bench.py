@@ -130,7 +130,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if os.environ.get('LVAE_BENCH_SINGLE_GPU_TEST') == '1':     # rehearsal of the N > 1 path on a 1-GPU box: all ranks on cuda:0, gloo
+            local_rank = 0
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
