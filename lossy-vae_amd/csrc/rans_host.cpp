@@ -14,6 +14,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -235,19 +239,76 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
 }
 
 namespace {
+// Persistent worker pool.  The coder is called 2 x (1 + 9) times per batch by two pipeline-group threads; spawning up to 35
+// std::threads per call put ~0.5-1 ms of thread creation on each call and made step times jittery.  Jobs are index ranges
+// [0, n) claimed with an atomic counter; callers take part in their own job and several callers may have jobs in flight.
+struct Job {
+    int n = 0, max_workers = 0;
+    std::atomic<int> next{0}, done{0}, workers{0};
+    void (*run)(void*, int) = nullptr;
+    void* ctx = nullptr;
+    std::mutex m;
+    std::condition_variable cv;
+};
+
+class Pool {
+public:
+    static Pool& get() { static Pool* p = new Pool;  return *p; }      // leaked on purpose: destroying a condition_variable with waiting
+                                                                        // (detached) workers at process exit blocks in pthread_cond_destroy
+    void submit(const std::shared_ptr<Job>& j) {
+        { std::lock_guard<std::mutex> l(m_); q_.push_back(j); }
+        cv_.notify_all();
+    }
+    int size() const { return (int)th_.size(); }
+private:
+    Pool() {
+        int n = (int)std::thread::hardware_concurrency();
+        if (n < 2) n = 2;
+        if (n > 64) n = 64;
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+        for (auto& t : th_) t.detach();            // workers live for the process; they only touch heap-owned jobs
+    }
+    void loop() {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return !q_.empty(); });
+                j = q_.front();
+                if (j->next.load() >= j->n || j->workers.load() >= j->max_workers) { q_.pop_front(); continue; }
+                j->workers.fetch_add(1);
+            }
+            work(*j);
+        }
+    }
+public:
+    static void work(Job& j) {
+        int did = 0;
+        for (int i; (i = j.next.fetch_add(1)) < j.n;) { j.run(j.ctx, i); ++did; }
+        if (did && j.done.fetch_add(did) + did == j.n) { std::lock_guard<std::mutex> l(j.m); j.cv.notify_all(); }
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> q_;
+    std::vector<std::thread> th_;
+};
+
 template <class F>
 void parallel_for(int n, int n_threads, F&& f) {
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n) n_threads = n;
     if (n_threads <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-    std::atomic<int> next{0};
-    auto worker = [&]() { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
-    std::vector<std::thread> th;
-    th.reserve(n_threads - 1);
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
+    auto j = std::make_shared<Job>();
+    j->n = n;
+    j->max_workers = n_threads - 1;                 // the caller is the n_threads-th worker
+    j->ctx = (void*)&f;
+    j->run = [](void* c, int i) { (*(typename std::remove_reference<F>::type*)c)(i); };
+    Pool::get().submit(j);
+    Pool::work(*j);
+    std::unique_lock<std::mutex> l(j->m);
+    j->cv.wait(l, [&] { return j->done.load() >= n; });
 }
 }  // namespace
 
