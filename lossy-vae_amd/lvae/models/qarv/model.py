@@ -208,6 +208,7 @@ class _NetPlan(Plan):
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
+        self.qcuts = []                         # encode plans: op index right after each block's quantize launch
         self.prm_ptrs, self.zhat_ptrs, self.zhat_bufs = [], [], []  # per latent block: raw prior conv output / latent buffer (scratch may be re-grown)
         self.lat_shapes = []                    # (z, HW)
 
@@ -349,6 +350,7 @@ class _EncPlan(_NetPlan):
                 self.sym_off.append(ioff)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
                                                  B, h * w, z, z), p + '.quantize')
+                self.qcuts.append(len(self.ops))        # this block's symbols and indexes are final from here on
                 if with_bits:       # eval-mode likelihood of the quantised latent (qarv/model.py:95-96), prm still holds this block
                     li = len(self.sym_off) - 1
                     self.add(lib.lvae_gaussian_nll_f32, (self.bufs['prm'].data_ptr(), ptr(self.sym_all, ioff), ptr(self.nats, li * B),
@@ -546,24 +548,42 @@ class VariableRateLossyVAE(CodecBase):
             pl = self._plan('enc', n, H, W, g)
             t0 = time.time()
             pl.im.view(n, 3, H, W).copy_(im[start:start + n])
-            pl.run(stream=stream.cuda_stream)
+            # Progressive hand-over: after each latent block's quantize launch, its symbols / indexes are copied to pinned host
+            # memory and an event is recorded; the host then entropy-codes block i while the GPU is still computing blocks > i
+            # (only the last block's streams are coded after the GPU has finished).
+            lo, evs = 0, []
+            for li, cut in enumerate(pl.qcuts):
+                pl.run(lo, cut, stream=stream.cuda_stream)
+                lo = cut
+                z, hw = pl.lat_shapes[li]
+                o, cnt = pl.sym_off[li], n * z * hw
+                pl.sym_host[o:o + cnt].copy_(pl.sym_all[o:o + cnt], non_blocking=True)
+                pl.idx_host[o:o + cnt].copy_(pl.idx_all[o:o + cnt], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                evs.append(ev)
+            pl.run(lo, None, stream=stream.cuda_stream)
             t1 = time.time()
-            pl.sym_host.copy_(pl.sym_all, non_blocking=True)
-            pl.idx_host.copy_(pl.idx_all, non_blocking=True)
+            nl = len(pl.lat_shapes)
+            per_block, t_wait = [], 0.0
+            for li, ev in enumerate(evs):
+                tw = time.time()
+                ev.synchronize()
+                t_wait += time.time() - tw
+                z, hw = pl.lat_shapes[li]
+                o = pl.sym_off[li]
+                sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
+                iv = [pl.idx_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
+                per_block.append(rans_encode_streams(tables, sv, iv, nthreads))
+            tw = time.time()
             stream.synchronize()
-            t2 = time.time()
-            sv, iv = [], []
-            for b in range(n):
-                for li, (z, hw) in enumerate(pl.lat_shapes):
-                    o = pl.sym_off[li] + b * z * hw
-                    sv.append(pl.sym_np[o:o + z * hw]); iv.append(pl.idx_np[o:o + z * hw])
-            strings = rans_encode_streams(tables, sv, iv, nthreads)
+            t2 = t1 + t_wait + (time.time() - tw)
+            strings = [per_block[li][b] for b in range(n) for li in range(nl)]
             if T is not None:
                 t3 = time.time()
                 T['enc_launch'] = T.get('enc_launch', 0) + t1 - t0
                 T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + t2 - t1
                 T['enc_rans'] = T.get('enc_rans', 0) + t3 - t2
-            nl = len(pl.lat_shapes)
             assert nl == self.num_latents
             return [header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]) for b in range(n)]
 
