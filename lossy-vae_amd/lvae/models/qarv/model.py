@@ -562,7 +562,8 @@ class VariableRateLossyVAE(CodecBase):
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 evs.append(ev)
-            pl.run(lo, None, stream=stream.cuda_stream)
+            # (the launches after the last quantize -- z_proj / resnet_end of the last latent block, which the reference also runs
+            # before it meets CompresionStopFlag -- do not influence the bitstream and are skipped)
             t1 = time.time()
             nl = len(pl.lat_shapes)
             per_block, t_wait = [], 0.0

@@ -16,6 +16,22 @@ def main(path, top=40):
     scols = [r[1] for r in cur.execute(f'pragma table_info({ks})')]
     namecol = 'display_name' if 'display_name' in scols else 'kernel_name'
     rows = cur.execute(f'select s.{namecol}, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id').fetchall()
+    iv = sorted(cur.execute(f'select d.start, d.end from {kd} d').fetchall())
+    busy, cur_s, cur_e, gaps = 0, None, None, []
+    for a, b in iv:
+        if cur_e is None or a > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+                gaps.append(a - cur_e)
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    if cur_e is not None:
+        busy += cur_e - cur_s
+    span = iv[-1][1] - iv[0][0] if iv else 1
+    big = sorted(gaps)[-20:]
+    print(f'# GPU busy (union of kernel intervals) {busy / 1e6:.1f} ms of a {span / 1e6:.1f} ms span = {100 * busy / span:.1f} %; '
+          f'{len(gaps)} idle gaps, {sum(gaps) / 1e6:.1f} ms in total, {sum(g for g in gaps if g > 50000) / 1e6:.1f} ms of it in gaps > 50 us')
     agg = {}
     for name, dur in rows:
         name = re.sub(r'\s+', ' ', name)
