@@ -98,3 +98,20 @@ def test_header_layout():
     # qarv/model.py:525-528,567: '2H'(h,w) | 'f'(lambda) | '3H'(nB,H/64,W/64) | 'B'(9) | '9I' | payload -> 51 bytes overhead
     body = struct.pack('f', 2048.0) + struct.pack('3H', 1, 8, 12) + coding.pack_byte_strings([b''] * 9)
     assert len(struct.pack('2H', 512, 768) + body) == 51
+
+
+def test_auto_ksplit_is_batch_independent_and_valid():
+    """lvae.engine.auto_ksplit takes the PER-IMAGE row count, so the number of K slices (and with it the summation order) cannot
+    depend on the batch size; every returned S divides the k-tile count and keeps >= 4 k-tiles per slice."""
+    from lvae import _native
+    from lvae.engine import auto_ksplit
+    RM = _native.ST_ROWMAJOR
+    for m1, N, K in [(96, 512, 1024), (96, 512, 2048), (384, 512, 1536), (384, 1024, 512), (1536, 384, 768), (1536, 96, 3456),
+                     (6144, 256, 448), (24576, 192, 384), (96, 32, 4608)]:
+        s = auto_ksplit(m1, N, K, RM, N, N, 2)
+        assert s >= 1 and (K // 32) % s == 0 and (s == 1 or K // 32 // s >= 4), (m1, N, K, s)
+    assert auto_ksplit(96, 512, 1024, RM, 512, 512, 2) > 1                 # stride-64 MLP: few tiles, long K
+    assert auto_ksplit(24576, 192, 384, RM, 192, 192, 2) == 1              # stride-4 layer: plenty of tiles
+    assert auto_ksplit(96, 512, 1000, RM, 512, 512, 2) == 1                # K not a multiple of 32
+    assert auto_ksplit(96, 510, 1024, RM, 510, 512, 2) == 1                # N not a multiple of 4
+    assert auto_ksplit(96, 512, 1024, _native.ST_SHUFFLE, 512, 512, 2) == 1
