@@ -242,17 +242,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
     // split-K (gridDim.y slices): this workgroup covers k16 stages [q0, q0 + nq); the slice offset goes into the buffer bases
     const int nq = d.K / 16 / (int)gridDim.y, q0 = (int)blockIdx.y * nq;
     const int rows_a = (d.M - m0) < C::BM ? (d.M - m0) : C::BM;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(d.A0 + (long)m0 * d.lda0 + q0 * 16), 0,
-                                                                         rows_a * d.lda0 * 4 - q0 * 64, 0x00020000);
+    // A = [A0 | A1] along K (fused torch.cat, qarv/model.py:66-67): stages below K0 stream from A0, the others from A1
+    const float* a0b = d.A0 + (long)m0 * d.lda0;
+    const float* a1p = d.A1 ? d.A1 : d.A0;
+    const long lda1 = d.A1 ? d.lda1 : d.lda0;
+    const float* a1b = a1p + (long)m0 * lda1;
+    const int n0rec = rows_a * d.lda0 * 4, n1rec = rows_a * (int)lda1 * 4;
+    const int qsplit = d.K0 / 16;                                 // first stage that reads A1
     const int rows_w = (d.N - n0) < C::BN ? (d.N - n0) : C::BN;
     const long wrow_b = (long)6 * d.K;                            // bytes per W row in the k16-interleaved copy
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(d.Wt16 + (long)3 * d.N * d.ldw + (long)n0 * 3 * d.K + q0 * 48), 0, (int)(rows_w * wrow_b) - q0 * 96, 0x00020000);
-    int a_voff[2], a_st[2], w_voff[NW], w_st[NW];
+    int a_voff[2], a_voff1[2], a_st[2], w_voff[NW], w_st[NW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = tid + 256 * j, row = perm(c >> 2), ak4 = c & 3;
         a_voff[j] = (row * d.lda0 + ak4 * 4) * 4;
+        a_voff1[j] = (row * (int)lda1 + ak4 * 4) * 4;
         a_st[j] = row * ROWB + ak4 * 8;
     }
 #pragma unroll
@@ -274,7 +280,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
 
     u32x4 ra[2][2], rb[2][NW];        // [stage parity][chunk]
     u32x2 sa[3];
-    auto load_a = [&](int par, int j, int q) { ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_voff[j], q * 64, 0); };
+    auto load_a = [&](int par, int j, int q) {      // q is slice-local; the source is chosen per stage with scalar selects (no branch:
+        const int qg = q0 + q;                        // a branch would cut the fenced MFMA / filler stream into basic blocks)
+        const bool second = qg >= qsplit;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a1b : a0b), 0, second ? n1rec : n0rec, 0x00020000);
+        ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, second ? a_voff1[j] : a_voff[j], (second ? qg - qsplit : qg) * 64, 0);
+    };
     auto load_w = [&](int par, int j, int q) { rb[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_voff[j], q * 96, 0); };
     auto split_half = [&](int par, int j, int h) {
         float x0 = __uint_as_float(ra[par][j][2 * h]), x1 = __uint_as_float(ra[par][j][2 * h + 1]);
@@ -415,13 +427,15 @@ int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
 // status), 0 otherwise (the caller falls back to gemm_x3_kernel).  force: 0 = choose; 1..3 = k16 kernel with TN = force;
 // 8 = the 8-wave 256 x 128 kernel (tuning hook LVAE_X3V2_TN).  Every choice gives the same bits.
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
-    if (d->prec != 2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || (d->K & 31) || (d->lda0 & 3) || d->ldw != d->K) return 0;
+    if (d->prec != 2 || d->a_mode != LVAE_A_PLAIN || (d->K & 31) || (d->lda0 & 3) || d->ldw != d->K) return 0;
+    const bool cat = d->K1 != 0;                                   // [A0 | A1]: k16 kernels only, stage-aligned split
+    if (cat && (!d->A1 || (d->K0 & 15) || (d->lda1 & 3) || (long)256 * d->lda1 * 4 > 0x7fffffffL)) return 0;
     if ((long)256 * d->lda0 * 4 > 0x7fffffffL || (long)6 * d->N * d->K > 0x7fffffffL) return 0;
     const int S = d->ksplit > 1 ? d->ksplit : 1;
     if (S > 1 && (d->K % (32 * S))) return 0;
     const int M = d->M, N = d->N, K = d->K / S;
     int sel = force;
-    if (S > 1 && sel == 8) sel = 0;
+    if ((S > 1 || cat) && sel == 8) sel = 0;
     if (sel <= 0) {
         // k16 kernels: rounds of 128 x 64c tiles over 2 x 256 workgroup slots x per-tile work / measured relative efficiency
         double best = 1e300;
@@ -435,7 +449,7 @@ int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* 
         // 8-wave 256 x 128 tiles, one per CU: better inside a tile (70 % vs 55 % MFMA-busy) but whole rounds of 256 tiles; taken when
         // the problem is one well-filled round and long enough to amortise the un-overlapped prologue / epilogue
         const long t8 = (long)((M + 255) / 256) * ((N + 127) / 128);
-        if (S == 1 && t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
+        if (S == 1 && !cat && t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
     }
     if (sel == 8) {
         *rc = d->a_gelu ? launch_w8<true>(d, st) : launch_w8<false>(d, st);

@@ -155,3 +155,35 @@ def test_gemm_x3_pipelined_kernel_is_bit_identical(M, N, K, epi, a_gelu):
         outs.append(out)
     assert not torch.isnan(outs[0]).any()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('M,N,K0,K1,epi', [(3000, 256, 256, 384, 0), (700, 384, 384, 512, 0), (260, 512, 512, 1024, 1), (5000, 128, 16, 48, 0)])
+def test_gemm_x3_concat_operand_is_bit_identical(M, N, K0, K1, epi):
+    """A = [A0 | A1] along K (the fused torch.cat of post_merge, qarv/model.py:66-67) on the pipelined kernel (cfg 0) against
+    gemm_x3_kernel (cfg -1), and against the same product on a materialised concatenation."""
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(M + N + K0 + K1)
+    K = K0 + K1
+    A0 = torch.randn(M, K0 + 4, generator=g).cuda()            # padded leading dimensions
+    A1 = torch.randn(M, K1 + 8, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    W3 = pack_bf16x3(Wt)
+    bias = torch.randn(N, generator=g).cuda()
+    outs = []
+    for cfg, cat in ((0, True), (-1, True), (0, False)):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        d = _native.GemmDesc()
+        if cat:
+            d.A0, d.lda0, d.K0, d.A1, d.lda1, d.K1 = A0.data_ptr(), K0 + 4, K0, A1.data_ptr(), K1 + 8, K1
+        else:
+            Ac = torch.cat([A0[:, :K0], A1[:, :K1]], 1).contiguous()
+            d.A0, d.lda0, d.K0 = Ac.data_ptr(), K, K
+        d.Wt, d.Wt16, d.ldw, d.bias, d.out, d.ldo = Wt.data_ptr(), W3.data_ptr(), K, bias.data_ptr(), out.data_ptr(), N
+        d.M, d.N, d.K, d.epi, d.prec, d.cfg = M, N, K, epi, 2, cfg
+        assert L.lvae_gemm_f32(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
