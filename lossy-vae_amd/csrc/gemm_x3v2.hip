@@ -57,13 +57,14 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 
 // ---------------------------------------------------------------------------------------------------------------------
 // gemm_x3w8_kernel: 256 x 128 tile, 8 waves (4 x 2, wave tile 64 x 64), ONE workgroup per CU, DOUBLE-buffered LDS
-// (2 x 384 rows x 208 B = 156 KiB).  In gemm_x3v2_kernel the ds_write phase between the two barriers costs ~1000 of a
-// k-tile's ~3900 cycles (tools/ubench/x3v2_trace.hip: the VGPR->LDS write path moves ~70 B/clk per CU and all four waves
+// (2 x 384 rows x 208 B = 156 KiB).  In a single-stage pipelined kernel (this file's first form, in the history) the ds_write phase
+// between the two barriers cost ~1000 of a k-tile's ~3900 cycles (in-kernel s_memtime timeline: the VGPR->LDS write path moves
+// ~70 B/clk per CU and all four waves
 // write at once) and starves the co-resident workgroup's ds_reads.  Here tile t+1 is split and written into the other LDS
 // stage by filler instructions in the MFMA shadows of tile t (chunk by chunk: split -> 3 x ds_write_b64 -> reload for t+2),
 // so a k-tile costs one barrier plus one exposed fragment read.  Staging rows are permuted (bit 0 <-> bit 2 of the row
 // index) so that the 16-lane (b64) / 8-lane (b128) LDS write groups cover 32 distinct banks (208-B rows: rows r and r+4 are
-// 16 banks apart) -- the unpermuted map of gemm_x3v2_kernel loses a third of its LDS write cycles to 2-way conflicts.
+// 16 banks apart) -- an unpermuted map loses a third of its LDS write cycles to 2-way conflicts (PMC SQ_LDS_BANK_CONFLICT).
 // Same per-accumulator MFMA sequence as the other two prec-2 kernels => bit-identical results.
 template <bool AGELU>
 __global__ __launch_bounds__(512, 1) void gemm_x3w8_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
@@ -209,7 +210,7 @@ int launch_w8(const lvae_gemm_desc* d, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// gemm_x3k16_kernel: the 4-wave 128 x (64*TN) tile of gemm_x3v2_kernel, two workgroups per CU, with DOUBLE-buffered LDS
+// gemm_x3k16_kernel: 4 waves, 128 x (64*TN) tiles, two workgroups per CU, with DOUBLE-buffered LDS
 // made affordable by 16-deep stages: 2 x (128 + 64*TN) rows x 112 B (3 planes x 32 B + 16 pad) = 70 KB for TN = 3.  Each
 // stage feeds one k16 MFMA step (12*TN MFMAs per wave); the next stage is split / written by fillers in those MFMAs'
 // shadows, so a stage costs ONE barrier and one exposed fragment read, and the ~1000-cycle ds_write phase of the k32
