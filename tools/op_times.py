@@ -20,7 +20,21 @@ def main():
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 768
     dev = torch.device('cuda:0')
-    model, _ = bench.build_model(dev)
+    name = os.environ.get('LVAE_MODEL', 'qarv_base')
+    if name == 'qarv_base':
+        model, _ = bench.build_model(dev)
+    else:                                                # qres34m / qres17m / qres34m_lossless with seeded weights
+        import lvae
+        import seeded_init
+        model = lvae.get_model(name)
+        sd = model.state_dict()
+        for k in list(sd.keys()):
+            a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0, profile='typical')
+            if a is not None and 'discrete_gaussian' not in k:
+                sd[k] = torch.from_numpy(a)
+        model.load_state_dict(sd)
+        model.compress_mode()
+        model = model.to(dev).eval()
     model.pipeline_groups = 1
     ims = bench.synth_batch(B, H, W, 0).to(dev)
     strings = model.compress_batch(ims)
