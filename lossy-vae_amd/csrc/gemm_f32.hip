@@ -714,7 +714,8 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
 }
 
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) {
-    if (d->prec == 2 && x3v2 && d->cfg == 0 && d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) {   // cfg -1: legacy kernel
+    if (d->prec == 2 && x3v2 && d->cfg == 0 &&
+        ((d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) || d->a_mode == LVAE_A_CONV3)) {   // cfg -1: legacy kernel
         int rc = 0;
         if (lvae_gemm_x3v2_try(d, st, x3v2_tn, &rc)) return rc;
     }

@@ -219,7 +219,7 @@ int launch_w8(const lvae_gemm_desc* d, hipStream_t st) {
 // buffer (lvae.models.base.pack_bf16x3): one stage of one row is 96 contiguous bytes.  Staging rows are enumerated
 // 0,2,4,6,1,3,5,7 so that every LDS write group (16 lanes b64 / 8 lanes b128) covers 32 distinct banks with 112-B rows.
 // Per accumulator: k16 steps in ascending k, six cross terms in gemm_x3_kernel's order => bit-identical to it.
-template <int TN, bool AGELU>
+template <int TN, bool AGELU, int AMODE>
 __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     using C = Cfg<2, 2, 2, TN, 1, 32>;
     constexpr int ROWB = 112, ROWS = 128 + 64 * TN, STAGE = ROWS * ROWB;
@@ -262,6 +262,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
         a_voff1[j] = (row * (int)lda1 + ak4 * 4) * 4;
         a_st[j] = row * ROWB + ak4 * 8;
     }
+    // 3x3-tap gather (implicit GEMM over an NHWC map, K = 9*Cin, tap-major): a stage of 16 channels lies inside one tap (Cin % 16
+    // == 0); the tap is a uniform offset added to the row's own pixel address, and a tap outside the image turns the address into an
+    // out-of-range one, i.e. a zero from the buffer unit -- no masks on the data path.
+    int tapok[2] = {0, 0};
+    if (AMODE == LVAE_A_CONV3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 256 * j, m = m0 + perm(c >> 2), ak4 = c & 3;
+            const int w = m % d.W, h = (m / d.W) % d.H;
+            a_voff[j] = m < d.M ? (int)(((long)m * d.K0 + ak4 * 4) * 4) : 0x7fffffff;
+#pragma unroll
+            for (int sidx = 0; sidx < 9; ++sidx) {
+                const int hh = h + sidx / 3 - 1, ww = w + sidx % 3 - 1;
+                tapok[j] |= (m < d.M && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? (1 << sidx) : 0;
+            }
+        }
+    }
+    const int a_all_rec = (AMODE == LVAE_A_CONV3) ? (int)((long)d.M * d.K0 * 4) : 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int c = (tid + 256 * j) % NWC, row = perm(c / 6), piece = c % 6;
@@ -283,6 +301,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
     u32x2 sa[3];
     auto load_a = [&](int par, int j, int q) {      // q is slice-local; the source is chosen per stage with scalar selects (no branch:
         const int qg = q0 + q;                        // a branch would cut the fenced MFMA / filler stream into basic blocks)
+        if (AMODE == LVAE_A_CONV3) {
+            const int kq = qg * 16, tap = kq / d.K0, kk = kq - tap * d.K0;              // uniform
+            int toff = (((tap / 3 - 1) * d.W + (tap % 3 - 1)) * d.K0 + kk) * 4;
+            asm volatile("" : "+s"(toff));          // computed here, unconditionally: otherwise hipcc sinks it into a divergent branch
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.A0, 0, a_all_rec, 0x00020000);
+            int vo = a_voff[j] + toff;
+            vo = ((tapok[j] >> tap) & 1) ? vo : 0x7fffffff;
+            ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            return;
+        }
         const bool second = qg >= qsplit;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a1b : a0b), 0, second ? n1rec : n0rec, 0x00020000);
@@ -407,17 +435,17 @@ int g_x3v2_lds_pad = 0;            // trace harness: extra dynamic LDS to force 
 constexpr int g_x3v2_lds_pad = 0;
 #endif
 
-template <int TN, bool AGELU>
+template <int TN, bool AGELU, int AMODE>
 int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BN = 64 * TN, LDS = 2 * (128 + BN) * 112;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3k16_kernel<TN, AGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 64 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3k16_kernel<TN, AGELU, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 64 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles_m = (d->M + 127) / 128, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU>), dim3(n_tiles, d->ksplit > 1 ? d->ksplit : 1), dim3(256), LDS + g_x3v2_lds_pad, st, *d,
+    hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU, AMODE>), dim3(n_tiles, d->ksplit > 1 ? d->ksplit : 1), dim3(256), LDS + g_x3v2_lds_pad, st, *d,
                        tiles_n, n_tiles);
     return (int)hipGetLastError();
 }
@@ -428,15 +456,17 @@ int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
 // status), 0 otherwise (the caller falls back to gemm_x3_kernel).  force: 0 = choose; 1..3 = k16 kernel with TN = force;
 // 8 = the 8-wave 256 x 128 kernel (tuning hook LVAE_X3V2_TN).  Every choice gives the same bits.
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
-    if (d->prec != 2 || d->a_mode != LVAE_A_PLAIN || (d->K & 31) || (d->lda0 & 3) || d->ldw != d->K) return 0;
+    const bool conv3 = d->a_mode == LVAE_A_CONV3;
+    if (d->prec != 2 || (d->a_mode != LVAE_A_PLAIN && !conv3) || (d->K & 31) || d->ldw != d->K) return 0;
+    if (!conv3 && (d->lda0 & 3)) return 0;
+    if (conv3 && ((d->K0 & 15) || d->K != 9 * d->K0 || d->K1 != 0 || d->H <= 0 || d->W <= 0 || (long)d->M * d->K0 * 4 > 0x7ffffff0L)) return 0;
     const bool cat = d->K1 != 0;                                   // [A0 | A1]: k16 kernels only, stage-aligned split
     if (cat && (!d->A1 || (d->K0 & 15) || (d->lda1 & 3) || (long)256 * d->lda1 * 4 > 0x7fffffffL)) return 0;
-    if ((long)256 * d->lda0 * 4 > 0x7fffffffL || (long)6 * d->N * d->K > 0x7fffffffL) return 0;
     const int S = d->ksplit > 1 ? d->ksplit : 1;
     if (S > 1 && (d->K % (32 * S))) return 0;
     const int M = d->M, N = d->N, K = d->K / S;
     int sel = force;
-    if ((S > 1 || cat) && sel == 8) sel = 0;
+    if ((S > 1 || cat || conv3) && sel == 8) sel = 0;
     if (sel <= 0) {
         // k16 kernels: rounds of 128 x 64c tiles over 2 x 256 workgroup slots x per-tile work / measured relative efficiency
         double best = 1e300;
@@ -450,14 +480,21 @@ int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* 
         // 8-wave 256 x 128 tiles, one per CU: better inside a tile (70 % vs 55 % MFMA-busy) but whole rounds of 256 tiles; taken when
         // the problem is one well-filled round and long enough to amortise the un-overlapped prologue / epilogue
         const long t8 = (long)((M + 255) / 256) * ((N + 127) / 128);
-        if (S == 1 && !cat && t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
+        if (S == 1 && !cat && !conv3 && t8 >= 176 && t8 <= 256 && K >= 512 && N % 128 == 0) sel = 8;
     }
     if (sel == 8) {
         *rc = d->a_gelu ? launch_w8<true>(d, st) : launch_w8<false>(d, st);
+    } else if (conv3) {
+        if (d->a_gelu) *rc = sel == 1 ? launch_k16<1, true, LVAE_A_CONV3>(d, st) : sel == 2 ? launch_k16<2, true, LVAE_A_CONV3>(d, st)
+                                                                               : launch_k16<3, true, LVAE_A_CONV3>(d, st);
+        else *rc = sel == 1 ? launch_k16<1, false, LVAE_A_CONV3>(d, st) : sel == 2 ? launch_k16<2, false, LVAE_A_CONV3>(d, st)
+                                                                        : launch_k16<3, false, LVAE_A_CONV3>(d, st);
     } else if (d->a_gelu) {
-        *rc = sel == 1 ? launch_k16<1, true>(d, st) : sel == 2 ? launch_k16<2, true>(d, st) : launch_k16<3, true>(d, st);
+        *rc = sel == 1 ? launch_k16<1, true, LVAE_A_PLAIN>(d, st) : sel == 2 ? launch_k16<2, true, LVAE_A_PLAIN>(d, st)
+                                                                  : launch_k16<3, true, LVAE_A_PLAIN>(d, st);
     } else {
-        *rc = sel == 1 ? launch_k16<1, false>(d, st) : sel == 2 ? launch_k16<2, false>(d, st) : launch_k16<3, false>(d, st);
+        *rc = sel == 1 ? launch_k16<1, false, LVAE_A_PLAIN>(d, st) : sel == 2 ? launch_k16<2, false, LVAE_A_PLAIN>(d, st)
+                                                                   : launch_k16<3, false, LVAE_A_PLAIN>(d, st);
     }
     return 1;
 }

@@ -187,3 +187,37 @@ def test_gemm_x3_concat_operand_is_bit_identical(M, N, K0, K1, epi):
         outs.append(out)
     assert not torch.isnan(outs[0]).any()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize('B,H,W,Cin,N,epi,a_gelu', [(2, 24, 40, 256, 8, 0, 0), (3, 9, 13, 96, 96, 1, 1), (1, 64, 96, 384, 32, 0, 0),
+                                                     (5, 16, 24, 512, 96, 0, 0), (2, 7, 5, 64, 200, 3, 0)])
+def test_gemm_x3_conv3_gather_is_bit_identical(B, H, W, Cin, N, epi, a_gelu):
+    """3x3-tap gather (posterior heads, qres VD blocks) on the pipelined kernel (out-of-image taps = out-of-range buffer reads) against
+    gemm_x3_kernel (cfg -1) and against F.conv2d in fp64."""
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(B + H + W + Cin + N)
+    M, K = B * H * W, 9 * Cin
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w4 = (torch.randn(N, Cin, 3, 3, generator=g) / K ** 0.5).cuda()
+    Wt = w4.permute(0, 2, 3, 1).reshape(N, K).contiguous()          # [N][(i, j, ci)]
+    W3 = pack_bf16x3(Wt)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    outs = []
+    for cfg in (0, -1):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = x.data_ptr(), Cin, Cin, Wt.data_ptr(), W3.data_ptr(), K
+        d.bias, d.res, d.ldres, d.out, d.ldo = bias.data_ptr(), res.data_ptr(), N, out.data_ptr(), N
+        d.M, d.N, d.K, d.epi, d.prec, d.a_mode, d.H, d.W, d.a_gelu, d.cfg = M, N, K, epi, 2, 2, H, W, a_gelu, cfg
+        assert L.lvae_gemm_f32(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+    xin = F.gelu(x.double()) if a_gelu else x.double()
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w4.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    ref = {0: ref, 1: F.gelu(ref), 3: res.double() + ref}[epi]
+    assert float((outs[0].double() - ref).abs().max()) < 3e-5
