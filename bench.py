@@ -257,13 +257,13 @@ def main():
     if roof is not None and args.precision == 'bf16x3' and (B, H, W) == (8, 512, 768):
         # PMC-measured HBM bytes per launch of the same launch family, from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # passes of this workload (tools/prof_round.sh -> tools/pmc_traffic.py); counters cannot be read from inside this process
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_v7.json')
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_v8.json')
         if os.path.exists(tp):
             tj = json.load(open(tp))
             roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 1e6)
             roof['traffic_note'] = ('bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over '
-                                    f"{tj['launches']} launches of this family (profiles/r01_pmc_gemm_traffic_v7.json, "
-                                    'profiles/r01_pmc_hbm_traffic_v7.txt); below the algorithmic bytes because producer outputs are '
+                                    f"{tj['launches']} launches of this family (profiles/r01_pmc_gemm_traffic_v8.json, "
+                                    'profiles/r01_pmc_hbm_traffic_v8.txt); below the algorithmic bytes because producer outputs are '
                                     'still resident in the 256 MiB Infinity Cache when the GEMM reads them')
     if rank == 0 and model.timing is not None:
         print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)

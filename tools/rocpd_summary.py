@@ -40,7 +40,7 @@ def main(path, top=40):
     fam = [0, 0]
     for name, a in agg.items():
         if (re.search(r'gemm(_x3|_bf16)?_kernel', name) and name.rstrip().endswith(', 0>(lvae_gemm_desc, int, int)')) or \
-                re.search(r'gemm_x3(k16|w8)_kernel', name):
+                re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel', name):
             fam[0] += a[0]; fam[1] += a[1]
     tot = sum(a[1] for a in agg.values())
     print(f'# {path}: {len(rows)} dispatches, total kernel time {tot / 1e6:.3f} ms')
