@@ -147,7 +147,12 @@ int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const
 /* Stem: NCHW image [B][3][H][W] in [0,1] -> (im+shift)*scale (qarv/model.py:221) -> conv 4x4/stride 4
  * (zoo.py:37) -> NHWC [B][H/4][W/4][Cout].  wt is [48][Cout] with k = (ci*4+i)*4+j. Cout <= 256, multiple of 64. */
 int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out,
-                  int B, int H, int W, int Cout, float im_shift, float im_scale, void* stream);
+                  int B, int H, int W, int Cout, float im_shift, float im_scale, int* range_flag, void* stream);
+/* range_flag (device int, may be NULL): bit 0 is OR-ed in when any input value lies outside [0, 1] or is NaN -- the reference's
+ * `assert 0 <= im.min() <= im.max() <= 1` (qarv/model.py:219-220, qresvae/model.py:492) without its device sync: the caller zeroes
+ * the flag once and reads it at a synchronisation point it already has.  lvae_range_flag_f32 is the same check as a stand-alone
+ * pass over n floats (n % 4 == 0) for encoders whose first layer is not this stem (qres17m). */
+int lvae_range_flag_f32(const float* x, long n, float lo, float hi, int* flag, void* stream);
 
 /* y[n] = (gelu_out? gelu : id)( sum_k Wt[n][k] * (gelu_in? gelu(x[k]) : x[k]) + b[n] ) -- the lambda-embedding
  * MLP (qarv/model.py:206-210) and all AdaLN `embedding_layer`s (common.py:123-127) as one concatenated GEMV. */

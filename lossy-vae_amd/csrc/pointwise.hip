@@ -370,12 +370,17 @@ int dispatch_dwln_c(int C, const float* x, const float* wt, const float* bias, c
 // ------------------------------------------------------------------------------------------------ stem
 // One block = 64 output pixels x Cout channels (thread n = output channel, its 48 weights live in registers; the
 // 64x48 preprocessed patch matrix is staged in LDS and read as wave-uniform broadcasts).
+// range_flag (optional): the reference's input contract `0 <= im.min() <= im.max() <= 1` (qarv/model.py:219-220, qresvae/model.py:492)
+// checked on the values this kernel loads anyway: bit 0 of *range_flag is set when any pixel is outside [0, 1] or NaN; the host
+// reads the flag at a synchronisation point it already has (no extra device sync, unlike the reference's .min()/.max()).
 __global__ void stem_kernel(const float* __restrict__ im, const float* __restrict__ wt, const float* __restrict__ bias,
-                            float* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M) {
+                            float* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M,
+                            int* __restrict__ range_flag) {
     __shared__ __attribute__((aligned(16))) float patch[64][48];
     const int n = threadIdx.x;
     const int Ho = H / 4, Wo = W / 4;
     const long p0 = (long)blockIdx.x * 64;
+    bool bad = false;
     for (int e = n; e < 64 * 48; e += blockDim.x) {
         const int j = e & 3, p = (e >> 2) & 63, ci_i = e >> 8;       // ci_i = ci*4 + i
         const long pg = p0 + p;
@@ -387,10 +392,12 @@ __global__ void stem_kernel(const float* __restrict__ im, const float* __restric
             const long b = bho / Ho;
             const int ci = ci_i >> 2, i = ci_i & 3;
             v = im[((b * 3 + ci) * H + (4 * ho + i)) * (long)W + 4 * wo + j];
+            bad |= !(v >= 0.0f && v <= 1.0f);
             v = (v + im_shift) * im_scale;
         }
         patch[p][ci_i * 4 + j] = v;
     }
+    if (range_flag && bad) atomicOr(range_flag, 1);
     float wr[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) wr[k] = wt[k * Cout + n];
@@ -656,11 +663,32 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
 }
 
 extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out, int B, int H, int W,
-                             int Cout, float im_shift, float im_scale, void* stream) {
+                             int Cout, float im_shift, float im_scale, int* range_flag, void* stream) {
     if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256) return -22;
     const long M = (long)B * (H / 4) * (W / 4);
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
-                       B, H, W, Cout, im_shift, im_scale, M);
+                       B, H, W, Cout, im_shift, im_scale, M, range_flag);
+    return (int)hipGetLastError();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void range_flag_kernel(const float* __restrict__ x, long n4, float lo, float hi, int* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !(v[e] >= lo && v[e] <= hi);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+}  // namespace
+
+extern "C" int lvae_range_flag_f32(const float* x, long n, float lo, float hi, int* flag, void* stream) {
+    if (!x || !flag || n <= 0 || (n & 3)) return -22;
+    const long n4 = n / 4;
+    long bx = (n4 + 256 * 8 - 1) / (256 * 8);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(range_flag_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, x, n4, lo, hi, flag);
     return (int)hipGetLastError();
 }
 
@@ -764,5 +792,5 @@ extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 8; }
+extern "C" int lvae_abi_version(void) { return 9; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

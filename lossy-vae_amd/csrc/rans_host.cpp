@@ -102,9 +102,12 @@ extern "C" int lvae_build_gaussian_tables(const float* scale_table, int n_scales
         max_len = std::max(max_len, 2 * centers[i] + 1);
     }
     if (max_len + 2 > row_stride) return -2;
+    // erf / erfc are evaluated in double and rounded once to float: a correctly rounded fp32 erf whatever the C library's erff
+    // does in its last ulp, so the tables (and with them every bitstream) do not depend on the libm / torch / device in use.
+    // Bit-identical to the reference-built tables of tests/golden/{discretized_gaussian,gaussian_conditional}_tables.npz.
     auto phi = [cdf_form](float v) -> float {
-        if (cdf_form == 0) return 0.5f * (1.0f + erff(v / (float)M_SQRT2));
-        return 0.5f * erfcf(-(float)M_SQRT1_2 * v);
+        if (cdf_form == 0) return 0.5f * (1.0f + (float)erf((double)(v / (float)M_SQRT2)));
+        return 0.5f * (float)erfc((double)(-(float)M_SQRT1_2 * v));
     };
     std::vector<float> pmf(max_len + 1);
     std::vector<uint32_t> cdf(max_len + 2);

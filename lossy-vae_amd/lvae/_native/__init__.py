@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 
@@ -48,7 +48,8 @@ SIGNATURES = {
     'lvae_gemm_num_configs': (_i, []),
     'lvae_gelu_f32': (_i, [_vp, _vp, _l, _vp]),
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
-    'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    'lvae_range_flag_f32': (_i, [_vp, _l, _f, _f, _vp, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -55,7 +55,10 @@ def autotune_gemm(lib, d, stream_ptr, device):
     return best
 
 
-KSPLIT = os.environ.get('LVAE_KSPLIT', '1') != '0'
+# Split-K policy constants.  They are part of the bitstream contract (the slice count fixes a GEMM's summation order, and encoder and
+# decoder priors must agree bit for bit), so they are compile-time constants of the package, not environment knobs.
+KSPLIT_MAX_TILES_PER_IMAGE = 96       # only the few-tile layers (stride-16..64 MLPs, 3x3 heads) are split
+KSPLIT_TARGET_WORKGROUPS = 256        # slices x tiles-per-image stays within one workgroup per CU
 
 
 def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
@@ -63,7 +66,7 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
     and single-image calls, and the encoder and decoder of one image size, use the same summation order).  Split-K is for the
     few-tile, long-K layers only (stride-16..64 MLPs, the 3x3 posterior heads; <= 96 tiles per image): there a workgroup's K loop, not the MFMA rate, sets
     the launch time (~1500 cycles per 16-deep stage whatever the tile)."""
-    if not KSPLIT or store != _native.ST_ROWMAJOR or (N & 3) or (ldo & 3) or (ldres & 3) or K % 32:
+    if store != _native.ST_ROWMAJOR or (N & 3) or (ldo & 3) or (ldres & 3) or K % 32:
         return 1
     nk = K // 32
     if prec == 1:
@@ -71,9 +74,9 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
             return 1
         nk = K // 64
     tiles1 = ((m1 + 127) // 128) * ((N + 63) // 64)
-    if tiles1 > int(os.environ.get("LVAE_KSPLIT_MAXT", "96")):
+    if tiles1 > KSPLIT_MAX_TILES_PER_IMAGE:
         return 1
-    limit = min(nk // 4, int(os.environ.get("LVAE_KSPLIT_TILES", "256")) // tiles1)   # >= 4 k-tiles (128 deep) per slice
+    limit = min(nk // 4, KSPLIT_TARGET_WORKGROUPS // tiles1)   # >= 4 k-tiles (128 deep) per slice
     best = 1
     for s in range(2, max(2, limit) + 1):
         if s <= limit and nk % s == 0:
@@ -113,6 +116,26 @@ class Plan:
         t = torch.empty(int(numel), dtype=dtype, device=self.device)
         self.keep.append(t)
         return t
+
+    # ---- input contract (reference: `assert 0 <= im.min() <= im.max() <= 1`, qarv/model.py:219-220, qresvae/model.py:492)
+    def alloc_range_flag(self):
+        """Device flag the stem kernel ORs a 1 into when it meets a pixel outside [0, 1] (or NaN) + its pinned host mirror."""
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self.range_flag.data_ptr()
+
+    def fetch_range_flag(self):
+        """Queue the 4-byte D2H copy of the flag on the current stream (call after the stem launch, before a sync/event)."""
+        if getattr(self, 'range_flag', None) is not None:
+            self.flag_host.copy_(self.range_flag, non_blocking=True)
+
+    def raise_if_out_of_range(self):
+        """After a synchronisation that covers fetch_range_flag(): raise like the reference's preprocess_input assert."""
+        if getattr(self, 'range_flag', None) is not None and int(self.flag_host[0]) != 0:
+            self.range_flag.zero_()
+            self.flag_host.zero_()
+            raise AssertionError('input image values must lie in [0, 1] (reference: preprocess_input, '
+                                 '`0 <= im.min() <= im.max() <= 1`)')
 
     # ---- recording
     def add(self, fn, args, label=''):
@@ -168,6 +191,9 @@ class Plan:
         runs eagerly (also warms one-time kernel attributes); the second use captures it into a hipGraph (all buffers are
         pre-allocated, so the capture contains kernel nodes only); later uses replay the graph with ONE host call instead
         of one ctypes call per launch."""
+        if torch.cuda.current_device() != self.device.index:      # launches go to the plan's GPU whatever the caller's current device
+            with torch.cuda.device(self.device):
+                return self.run(lo, hi, stream)
         cur = torch.cuda.current_stream(self.device)
         s = stream if stream is not None else cur.cuda_stream
         key = (lo, hi)

@@ -1,5 +1,6 @@
 """Shared host-side machinery of the codecs: batch -> pipeline groups (one HIP stream + one host thread each, so that a
 group's host rANS coding overlaps the other group's GPU work), coder thread budget."""
+import functools
 import os
 
 import torch
@@ -32,25 +33,60 @@ def pack_bf16x3(t):
     return torch.cat([planes.reshape(-1), inter.reshape(-1)])
 
 
+class LazyW16:
+    """{address of an fp32 GEMM weight: address of its reduced-precision copy}, filled ON FIRST USE by Plan.gemm: only tensors
+    that are actually passed as `Wt` get a bf16 / bf16x3 copy (the packed dict also holds the AdaLN matrix, depthwise tables,
+    biases ... which never are).  Thread-safe: plans are recorded concurrently by the pipeline-group threads."""
+
+    def __init__(self, tensors, mode):
+        self.by_ptr = {t.data_ptr(): t for t in tensors.values()
+                       if t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 8 == 0}
+        self.mode, self.map, self.keep = mode, {}, []
+
+    def get(self, ptr):
+        h = self.map.get(ptr)
+        if h is not None:
+            return h
+        t = self.by_ptr.get(ptr)
+        if t is None:
+            return None
+        with _W16_LOCK:
+            h = self.map.get(ptr)
+            if h is None:
+                c = pack_bf16x3(t) if self.mode == 'bf16x3' else t.to(torch.bfloat16).contiguous()
+                self.keep.append(c)
+                h = self.map[ptr] = c.data_ptr()
+        return h
+
+
 def bf16x3_weight_map(tensors):
-    keep, amap = [], {}
-    for name, t in tensors.items():
-        if t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 8 == 0:
-            h = pack_bf16x3(t)
-            keep.append(h)
-            amap[t.data_ptr()] = h.data_ptr()
-    return amap, keep
+    m = LazyW16(tensors, 'bf16x3')
+    return m, m.keep
 
 
 def bf16_weight_map(tensors):
-    """{address of fp32 GEMM weight: bf16 copy} for every 2-D packed weight (kept alive by the returned holder list)."""
-    keep, amap = [], {}
-    for name, t in tensors.items():
-        if t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 8 == 0:
-            h = t.to(torch.bfloat16).contiguous()
-            keep.append(h)
-            amap[t.data_ptr()] = h.data_ptr()
-    return amap, keep
+    m = LazyW16(tensors, 'bf16')
+    return m, m.keep
+
+
+# GEMM arithmetic of newly built models, read ONCE at import (LVAE_PRECISION=fp32|bf16|bf16x3).  A bitstream decodes only under the
+# arithmetic that produced it (the priors must match bit for bit) and the container -- the reference's, byte for byte -- does not
+# record it: the default is fixed (bf16x3), an explicit mode must be set identically on both sides (docs: DESIGN.md 4).
+DEFAULT_PRECISION = os.environ.get('LVAE_PRECISION', 'bf16x3')
+assert DEFAULT_PRECISION in ('fp32', 'bf16', 'bf16x3'), DEFAULT_PRECISION
+
+
+def on_model_device(fn):
+    """Entry points that launch raw HIP kernels run with the MODEL's GPU as the current device (the launches go to streams of
+    that device; the caller's current device may be another GPU of the node)."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        dev = self._dummy.device
+        if dev.type == 'cuda' and torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):
+                return fn(self, *a, **k)
+        return fn(self, *a, **k)
+    return wrapper
 
 
 class CodecBase(nn.Module):
@@ -62,8 +98,7 @@ class CodecBase(nn.Module):
         self._streams = []
         self._pool = None
         # default: fp32-class accuracy on the bf16 matrix cores (same parity as the exact fp32 MFMA path, 1.2-1.5x faster)
-        self._prec = os.environ.get('LVAE_PRECISION', 'bf16x3')
-        assert self._prec in ('fp32', 'bf16', 'bf16x3')
+        self._prec = DEFAULT_PRECISION
 
     def set_gemm_precision(self, mode):
         """'fp32': exact fp32 MFMA (fmaf chains); 'bf16x3': fp32-class accuracy from three-term bf16 splits on the bf16 MFMA

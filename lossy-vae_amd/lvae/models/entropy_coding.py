@@ -8,9 +8,9 @@ Mirrors the reference's `DiscretizedGaussian` (lvae/models/entropy_coding.py:52-
   * `build_indexes` / `quantize` / `dequantize` run inside HIP kernels (lvae_prior_index_f32, lvae_quantize_f32,
     lvae_dequantize_f32) on uint8 indexes / int32 symbols, never as 63 compare passes or Python lists,
   * streams are produced by the native multi-threaded rANS coder (`lvae_rans_*_batch`).
-The pmf itself is evaluated with the same torch ops, on the module's device, as the reference does
-(`td.Normal.cdf` = 0.5*(1+erf(x/sqrt2)) in fp32 for QARV; 0.5*erfc(-x/sqrt2) for QRes), so the tables are
-bit-identical to the reference's on the same device.
+The pmf follows the reference's fp32 expression (`td.Normal.cdf` = 0.5*(1+erf(x/sqrt2)) for QARV; 0.5*erfc(-x/sqrt2) for
+QRes) but is ALWAYS evaluated on the host by `lvae_build_gaussian_tables` with a correctly rounded erf -- never by the GPU's
+torch.erf -- so the tables are bit-identical to the ones the reference builds on the CPU whatever device the module lives on.
 """
 import ctypes
 import math
@@ -69,35 +69,32 @@ class DiscretizedGaussian(nn.Module):
 
     @torch.no_grad()
     def update(self):
-        """GaussianConditional.update(): builds int32[n, max_len+2] CDF rows."""
+        """GaussianConditional.update(): builds int32[n, max_len+2] CDF rows.
+
+        The rows come from the native `lvae_build_gaussian_tables` (host C++: pmf in fp32 exactly as the reference's torch
+        expression, erf/erfc correctly rounded from double, CompressAI's pmf_to_quantized_cdf) -- NOT from torch.erf on the
+        module's device: a bitstream must decode on any box, so its tables may not depend on a GPU's (or a torch build's)
+        last-ulp erf.  Bit-identical to the tables the reference builds on the CPU (tests/test_host_coder.py, both CDF forms)."""
         lib = _native.lib()
-        multiplier = -scipy.stats.norm.ppf(self.tail_mass / 2)
-        table = self.scale_table
-        pmf_center = torch.ceil(table * multiplier).int()
-        pmf_length = 2 * pmf_center + 1
-        max_length = int(torch.max(pmf_length).item())
-        samples = torch.abs(torch.arange(max_length, device=table.device).int() - pmf_center[:, None]).float()
-        scale = table.unsqueeze(1).float()
-        upper = self._standardized_cumulative((0.5 - samples) / scale)
-        lower = self._standardized_cumulative((-0.5 - samples) / scale)
-        pmf = (upper - lower).cpu().numpy()
-        tail = (2 * lower[:, :1]).cpu().numpy()
-        lengths = pmf_length.cpu().numpy()
-        n = len(lengths)
-        cdf = np.zeros((n, max_length + 2), dtype=np.int32)
-        for i in range(n):
-            L = int(lengths[i])
-            prob = np.ascontiguousarray(np.concatenate([pmf[i, :L], tail[i]]).astype(np.float32))
-            row = np.zeros(L + 2, dtype=np.uint32)
-            rc = lib.lvae_pmf_to_quantized_cdf(prob.ctypes.data, L + 1, self.entropy_coder_precision, row.ctypes.data)
-            if rc != 0:
-                raise ValueError(f'pmf_to_quantized_cdf failed for scale {i}: rc={rc}')
-            cdf[i, :L + 2] = row.astype(np.int32)
-        dev = table.device
+        multiplier = float(-scipy.stats.norm.ppf(self.tail_mass / 2))
+        table = np.ascontiguousarray(self.scale_table.detach().cpu().numpy().astype(np.float32))
+        n = int(table.size)
+        if n == 0:
+            raise ValueError('empty scale table')
+        centers = np.ceil(table * np.float32(multiplier)).astype(np.int64)
+        stride = int(2 * centers.max() + 1) + 2
+        cdf = np.zeros((n, stride), dtype=np.int32)
+        cdf_len = np.zeros(n, dtype=np.int32)
+        offset = np.zeros(n, dtype=np.int32)
+        rc = lib.lvae_build_gaussian_tables(table.ctypes.data, n, multiplier, 0 if self.cdf_form == 'erf' else 1,
+                                            cdf.ctypes.data, stride, cdf_len.ctypes.data, offset.ctypes.data)
+        if rc != stride:
+            raise ValueError(f'lvae_build_gaussian_tables failed: rc={rc} (expected row length {stride})')
+        dev = self.scale_table.device
         self._quantized_cdf = torch.from_numpy(cdf).to(dev)
-        self._offset = (-pmf_center).to(dev)
-        self._cdf_length = (pmf_length + 2).to(dev)
-        self._host = None
+        self._offset = torch.from_numpy(offset).to(dev)
+        self._cdf_length = torch.from_numpy(cdf_len).to(dev)
+        self._host = (cdf, cdf_len, offset)
 
     def host_tables(self):
         """(qcdf int32 [n][stride], cdf_len int32 [n], offset int32 [n]) as contiguous numpy arrays."""

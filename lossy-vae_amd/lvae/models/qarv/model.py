@@ -24,7 +24,7 @@ import torch.nn as nn
 from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
-from ..base import CodecBase
+from ..base import CodecBase, on_model_device
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 
 EMBED_DIM = 256
@@ -302,7 +302,7 @@ class _EncPlan(_NetPlan):
                 h, w = h // 4, w // 4
                 x = self.new(B * h * w * m.out_channels)
                 self.add(lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
-                                             m.out_channels, model.im_shift, model.im_scale), p + '.stem')
+                                             m.out_channels, model.im_shift, model.im_scale, self.alloc_range_flag()), p + '.stem')
                 self.flops += 2 * B * h * w * m.out_channels * 48
             elif m.kind == 'down':
                 h, w = h // 2, w // 2
@@ -482,6 +482,9 @@ class VariableRateLossyVAE(CodecBase):
         lmb = float(np.float32(lmb))
         if self._cur_lmb == lmb:
             return
+        if torch.cuda.current_device() != pk.adaln.device.index:   # raw launches below: make the model's GPU the current one
+            with torch.cuda.device(pk.adaln.device):
+                return self._set_lmb(lmb)
         s = np.log(np.float32(lmb)) * np.float32(self._sin_period) / np.float32(math.log(self.MAX_LMB))
         dim = self.lmb_embed_dim[0]
         expo = np.linspace(0, 1, dim // 2, dtype=np.float32)
@@ -530,6 +533,7 @@ class VariableRateLossyVAE(CodecBase):
         self.compressing = mode
 
     @torch.no_grad()
+    @on_model_device
     def compress_batch(self, im, lmb=None):
         """Encode a (B,3,H,W) batch -> list of B byte strings (each identical to `compress(im[b:b+1])`)."""
         lmb = lmb or self.default_lmb
@@ -559,6 +563,8 @@ class VariableRateLossyVAE(CodecBase):
                 o, cnt = pl.sym_off[li], n * z * hw
                 pl.sym_host[o:o + cnt].copy_(pl.sym_all[o:o + cnt], non_blocking=True)
                 pl.idx_host[o:o + cnt].copy_(pl.idx_all[o:o + cnt], non_blocking=True)
+                if li == 0:
+                    pl.fetch_range_flag()
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 evs.append(ev)
@@ -571,6 +577,8 @@ class VariableRateLossyVAE(CodecBase):
                 tw = time.time()
                 ev.synchronize()
                 t_wait += time.time() - tw
+                if li == 0:
+                    pl.raise_if_out_of_range()
                 z, hw = pl.lat_shapes[li]
                 o = pl.sym_off[li]
                 sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
@@ -600,6 +608,7 @@ class VariableRateLossyVAE(CodecBase):
         return self.compress_batch(im, lmb)[0]
 
     @torch.no_grad()
+    @on_model_device
     def decompress_batch(self, strings):
         """Decode a list of byte strings that share lambda and latent shape -> (B,3,H,W) tensor in [0,1]."""
         B = len(strings)
@@ -672,6 +681,7 @@ class VariableRateLossyVAE(CodecBase):
 
     # ---- coder-free paths
     @torch.no_grad()
+    @on_model_device
     def estimate(self, im, lmb=None):
         """Eval-mode forward (forward_end2end in eval mode, qarv/model.py:94-97,294-315) without entropy coding:
         returns (im_hat (B,3,H,W) in [0,1], nats (num_latents, B) float64 = sum(-ln P) per latent block and image)."""
@@ -684,12 +694,16 @@ class VariableRateLossyVAE(CodecBase):
         enc.im.view(B, 3, H, W).copy_(im)
         enc.nats.zero_()
         enc.run()
+        enc.fetch_range_flag()
+        torch.cuda.current_stream(enc.device).synchronize()
+        enc.raise_if_out_of_range()
         # the encoder stops at CompresionStopFlag; reconstruct by feeding its symbols to the decode plan (same latent layout)
         dec.sym_all.copy_(enc.sym_all)
         dec.run()
         return dec.out.clone(), enc.nats.view(self.num_latents, B).clone()
 
     @torch.no_grad()
+    @on_model_device
     def conditional_sample(self, lmb, latents, emb=None, bhw_repeat=None, t=1.0, seed=None, return_latents=False):
         """Decoder output conditioned on a list of latents (qarv/model.py:365-395).  latents[i] is a (B, z_i, h_i, w_i) tensor on
         the model device (integer + prior mean, what `get_latents` / the decoder produce) or None; a missing latent is drawn from
@@ -725,12 +739,13 @@ class VariableRateLossyVAE(CodecBase):
                     used.append(zs.permute(0, 2, 1).reshape(B, zdim, *pl.lat_hw[li]).clone())
             else:
                 assert tuple(latents[li].shape) == (B, zdim, *pl.lat_hw[li]), f'latent {li}: shape {tuple(latents[li].shape)}'
-                pm = pl.pm_bufs[li].view(B, hw, zdim)
-                zt = latents[li].to(pm.device, torch.float32).permute(0, 2, 3, 1).reshape(B, hw, zdim)
-                sym = torch.round(zt - pm).to(torch.int32).permute(0, 2, 1).reshape(-1)      # NCHW raster order
-                o = pl.sym_off[li]
-                pl.sym_all[o:o + sym.numel()].copy_(sym)
-                lo = cut
+                # the supplied latent is used VERBATIM (qarv/model.py:101-103, `z = latent`): it goes straight into this block's
+                # z buffer (NCHW -> NHWC rows) and the dequantize launch at `cut` is skipped -- no re-quantisation against the
+                # current prior mean, so edited / interpolated latents and the 'exclude' / 'reverse' / 'single' modes of
+                # scripts/qarv/robust-decoding.py behave as in the reference
+                zt = latents[li].to(pl.device, torch.float32).permute(0, 2, 3, 1).reshape(-1)
+                pl.zhat_bufs[li][:zt.numel()].copy_(zt)
+                lo = cut + 1
                 if return_latents:
                     used.append(latents[li])
         pl.run(lo, None)
@@ -798,6 +813,7 @@ class VariableRateLossyVAE(CodecBase):
 
     # ---- debugging / test access (not on the hot path)
     @torch.no_grad()
+    @on_model_device
     def encode_trace(self, im, lmb=None):
         """Run the encode plan and return per-block int arrays (symbols, indexes in NCHW order) for parity tests."""
         lmb = lmb or self.default_lmb
@@ -806,7 +822,9 @@ class VariableRateLossyVAE(CodecBase):
         pl = self._plan('enc', B, H, W)
         pl.im.view(B, 3, H, W).copy_(im)
         pl.run()
+        pl.fetch_range_flag()
         torch.cuda.current_stream(pl.device).synchronize()
+        pl.raise_if_out_of_range()
         sym, idx = pl.sym_all.cpu().numpy(), pl.idx_all.cpu().numpy()
         out = []
         h, w = H // 64, W // 64

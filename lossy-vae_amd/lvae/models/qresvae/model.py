@@ -22,7 +22,7 @@ import torch.nn as nn
 from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
-from ..base import CodecBase
+from ..base import CodecBase, on_model_device
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 from ..qarv.model import UpParams, _conv
 
@@ -280,7 +280,7 @@ class _QresPlan(Plan):
                     h, w = h // 4, w // 4
                     x = self.new(B * h * w * m.out_channels)
                     self.add(lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
-                                                 m.out_channels, model.im_shift, model.im_scale), p + '.stem')
+                                                 m.out_channels, model.im_shift, model.im_scale, self.alloc_range_flag()), p + '.stem')
                 elif m.kind == 'cnx':
                     self.cnx(p, m, x.data_ptr(), x.data_ptr(), h, w)
                 else:           # CNX out of place (x is this level's encoder feature), then 2x2/s2 conv
@@ -505,10 +505,13 @@ class HierarchicalVAE(CodecBase):
                     dg._quantized_cdf, dg._offset, dg._cdf_length, dg._host = first._quantized_cdf, first._offset, first._cdf_length, None
             if isinstance(self.out_net, GaussianNLLOutParams):            # (:645-646)
                 self.out_net.update()
-                self._packed, self._plans = None, {}
+            # the packed device copy holds the scale table: one built before this call (encode_trace(), or a compress() that
+            # stopped at 'Uninitialized CDFs') would keep the empty pre-update table
+            self._packed, self._plans = None, {}
         self.compressing = mode
 
     @torch.no_grad()
+    @on_model_device
     def compress_batch(self, im):
         """(B,3,H,W) -> list of B compressed objects, each `[ [bytes] x 12, (1, C, H/64, W/64) ]` as `compress()` returns."""
         assert im.dim() == 4 and im.shape[1] == 3
@@ -529,7 +532,9 @@ class HierarchicalVAE(CodecBase):
             if pl.lossless:
                 pl.px_sym_host.copy_(pl.px_sym, non_blocking=True)
                 pl.px_idx_host.copy_(pl.px_idx, non_blocking=True)
+            pl.fetch_range_flag()
             stream.synchronize()
+            pl.raise_if_out_of_range()
             sv, iv = [], []
             for b in range(n):
                 for li, (z, hw) in enumerate(pl.lat_shapes):
@@ -559,6 +564,7 @@ class HierarchicalVAE(CodecBase):
         return self.compress_batch(im)[0]
 
     @torch.no_grad()
+    @on_model_device
     def decompress_batch(self, objs):
         B = len(objs)
         lossless = isinstance(self.out_net, GaussianNLLOutParams)
@@ -629,6 +635,7 @@ class HierarchicalVAE(CodecBase):
         return self.decompress(obj)[:, :, :img_h, :img_w]
 
     @torch.no_grad()
+    @on_model_device
     def encode_trace(self, im):
         B, _, H, W = im.shape
         self._prepare()

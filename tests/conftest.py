@@ -58,3 +58,37 @@ def product_model(qarv_seeded_sd):
     m.eval()
     m.compress_mode()
     return m
+
+
+# ----------------------------------------------------------------------------------------------- parity report
+# Every golden-parity test records one row per (model, size, lambda, precision) case: symbol flips, scale-index flips, number of
+# latent elements, max|dx_hat| against the reference's reconstruction and whether every rANS stream was byte-identical.  The rows are
+# printed in pytest's terminal summary (so the driver's log tail shows them even under -q) and written to
+# gpurun_out/parity_report.json.
+PARITY_ROWS = []
+
+
+def parity_record(case, sym_flips, idx_flips, n, max_dx, streams_identical):
+    PARITY_ROWS.append(dict(case=case, sym_flips=int(sym_flips), idx_flips=int(idx_flips), n=int(n),
+                            max_dx=None if max_dx is None else float(max_dx), streams_identical=bool(streams_identical)))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not PARITY_ROWS:
+        return
+    import json
+    tr = terminalreporter
+    tr.section('parity vs reference goldens: case sym_flips/idx_flips/n max|dx| streams')
+    for r in PARITY_ROWS:
+        dx = 'n/a' if r['max_dx'] is None else f"{r['max_dx']:.2e}"
+        tr.write_line(f"{r['case']}: {r['sym_flips']}/{r['idx_flips']}/{r['n']} {dx} {'same' if r['streams_identical'] else 'DIFF'}")
+    clean = sum(1 for r in PARITY_ROWS if r['sym_flips'] == 0 and r['idx_flips'] == 0)
+    tr.write_line(f'{clean} of {len(PARITY_ROWS)} cases flip-free; worst max|dx| '
+                  f"{max((r['max_dx'] or 0.0) for r in PARITY_ROWS):.2e} (bar 1e-4)")
+    try:
+        out = os.path.join(REPO, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_report.json'), 'w') as f:
+            json.dump(PARITY_ROWS, f, indent=1)
+    except OSError:
+        pass

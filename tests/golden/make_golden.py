@@ -210,6 +210,39 @@ def golden_progressive(model, h, w, lmb, tag, img_seed=0):
 
 
 @torch.no_grad()
+def golden_robust(model, h, w, lmb, tag, img_seed=0):
+    """The other three decodings of scripts/qarv/robust-decoding.py:44-49 ('exclude', 'reverse', 'single') plus one EDITED latent:
+    conditional_sample must use a supplied latent verbatim (qarv/model.py:101-103) even when the prior means of that block differ
+    from the ones that produced it (an earlier block is missing / edited).  t = 0: missing latents = prior mean."""
+    im, _ = image_tensor(h, w, img_seed)
+    model.eval()
+    _, stats_all = model.forward_end2end(im, lmb=model.expand_to_tensor(lmb, n=1), get_latent=True)
+    L = len(stats_all)
+    zs = [st['z'] for st in stats_all]
+    out = {'hw': np.array([h, w]), 'img_seed': np.array(img_seed), 'lmb': np.array(float(lmb))}
+    for i, z in enumerate(zs):
+        out[f'z{i}'] = npf(z)
+    bhw = (1, h // 64, w // 64)
+    cases = {}
+    for a in (0, 4, 8):
+        cases[f'exclude{a}'] = [None if i == a else z for i, z in enumerate(zs)]
+    for a in (2, 6):
+        cases[f'reverse{a}'] = [None if i < a else z for i, z in enumerate(zs)]
+    for a in (0, 3, 8):
+        cases[f'single{a}'] = [z if i == a else None for i, z in enumerate(zs)]
+    edited = [z.clone() for z in zs]
+    edited[1] = edited[1] * 0.5 + 0.25            # off the integer grid of its prior mean
+    edited[5] = torch.flip(edited[5], dims=[3]) * 0.75
+    cases['edited'] = edited
+    out['edited.z1'], out['edited.z5'] = npf(edited[1]), npf(edited[5])
+    for name, lat in cases.items():
+        x = model.conditional_sample(lmb=lmb, latents=lat, bhw_repeat=bhw, t=0)
+        out[f'x.{name}'] = npf(x).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}_robust.npz'), **out)
+    print('robust', tag, sorted(cases))
+
+
+@torch.no_grad()
 def golden_qres(model, h, w, tag, img_seed=0, model_name='qres34m'):
     """qres34m (qresvae/model.py:649-725): per-block indexes/symbols/strings, reconstruction, pickle container size."""
     import pickle
@@ -337,6 +370,11 @@ def main():
         load_seeded(model, 0)
         model.eval()
         return golden_progressive(model, 64, 128, 16.0, '64x128')
+    if len(sys.argv) > 1 and sys.argv[1] == 'robust':
+        model = lvae.get_model('qarv_base')
+        load_seeded(model, 0)
+        model.eval()
+        return golden_robust(model, 64, 64, 64.0, '64x64', img_seed=5)
     golden_pack()
     golden_cnx_block()
     model = lvae.get_model('qarv_base')

@@ -49,4 +49,5 @@ def test_argument_validation_without_gpu():
     assert L.lvae_gemm_f32(None, None) == -22
     assert L.lvae_dwconv_ln_f32(None, None, None, None, None, None, None, None, 1, 1, 1, 128, 7, None) == -22
     assert L.lvae_gemv_f32(None, None, None, None, 4, 4, 0, 0, None) == -22
-    assert L.lvae_stem_f32(None, None, None, None, 1, 64, 64, 192, 0.0, 1.0, None) == -22
+    assert L.lvae_stem_f32(None, None, None, None, 1, 64, 64, 192, 0.0, 1.0, None, None) == -22
+    assert L.lvae_range_flag_f32(None, 16, 0.0, 1.0, None, None) == -22

@@ -205,11 +205,25 @@ def test_stem(L):
     sh, sc = -0.4546259594901961, 3.67572653978347
     ref = F.conv2d((im.double() + sh) * sc, w.double(), b.double(), stride=4).permute(0, 2, 3, 1)
     out = torch.full((B, H // 4, W // 4, Cout), float('nan'), device='cuda')
-    rc = L.lvae_stem_f32(im.data_ptr(), w.reshape(Cout, 48).t().contiguous().data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W,
-                         Cout, sh, sc, _st())
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    wt = w.reshape(Cout, 48).t().contiguous()
+    rc = L.lvae_stem_f32(im.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cout, sh, sc, flag.data_ptr(), _st())
     assert rc == 0
     torch.cuda.synchronize()
     assert (out.double() - ref).abs().max().item() < 2e-5
+    assert int(flag.item()) == 0                                   # every value in [0, 1]
+    # the reference's input contract (qarv/model.py:219-220): out-of-range or NaN pixels raise the flag; NULL flag = unchecked
+    for bad in (1.0000001, -1e-6, float('nan')):
+        im2 = im.clone(); im2[1, 2, 5, 7] = bad
+        flag.zero_()
+        assert L.lvae_stem_f32(im2.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cout, sh, sc, flag.data_ptr(), _st()) == 0
+        assert int(flag.item()) == 1, bad
+        flag.zero_()
+        assert L.lvae_range_flag_f32(im2.data_ptr(), im2.numel(), 0.0, 1.0, flag.data_ptr(), _st()) == 0
+        assert int(flag.item()) == 1, bad
+    flag.zero_()
+    assert L.lvae_range_flag_f32(im.data_ptr(), im.numel(), 0.0, 1.0, flag.data_ptr(), _st()) == 0 and int(flag.item()) == 0
+    assert L.lvae_stem_f32(im.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cout, sh, sc, None, _st()) == 0
 
 
 def test_gemv(L):

@@ -19,12 +19,17 @@ import torch
 import seeded_init
 
 pytestmark = pytest.mark.gpu
-FLIP_BUDGET = 1e-3
+FLIP_BUDGET = 1e-3        # live-oracle comparisons on images without a committed golden (not the golden-parity bar below)
 
 
 def _img(h, w, seed, kind='natural'):
     u8 = seeded_init.synthetic_image_u8(h, w, seed, kind)
     return torch.from_numpy(u8).permute(2, 0, 1).float().div(255).unsqueeze(0)
+
+
+# Absolute ceilings per (size, lambda, precision) case, equal to what the MI355X shows today: no symbol flip at
+# all, at most one scale index (a sigma within 1e-6 of a table threshold) -- north_star: "quantized-latent indices bit-exact".
+MAX_SYM_FLIPS, MAX_IDX_FLIPS = 0, 1
 
 
 @pytest.mark.parametrize('prec', ['bf16x3', 'fp32'])
@@ -34,50 +39,66 @@ def test_golden_symbols_and_reconstruction(product_model, golden_dir, tag, seed,
     m = product_model
     m.set_gemm_precision(prec)
     try:
-        _golden_case(m, golden_dir, tag, seed)
+        _golden_case(m, golden_dir, tag, seed, prec)
     finally:
         m.set_gemm_precision('bf16x3')
 
 
-def _golden_case(m, golden_dir, tag, seed):
+def _golden_case(m, golden_dir, tag, seed, prec):
+    from conftest import parity_record
+    from lvae.models.entropy_coding import rans_encode_streams
+    from lvae.utils import coding
     g = np.load(os.path.join(golden_dir, f'qarv_base_{tag}.npz'))
     h, w = g['hw'].tolist()
     im = _img(h, w, seed).cuda()
-    report = {}
-    for lmb in g['lmbs'].tolist():
+    tables = m._dg().host_tables()
+    clean = 0
+    lmbs = g['lmbs'].tolist()
+    for lmb in lmbs:
         key = f'lmb{int(lmb)}'
+        case = f'qarv_base {tag} lmb={int(lmb)} {prec}'
         tr = m.encode_trace(im, lmb)
+        string = m.compress(im, lmb)
+        assert string[:10] == g[f'{key}.bitstream'].tobytes()[:10]                   # header: lambda, (1, nH, nW)
+        streams = coding.unpack_byte_string(string[10:])
+        assert len(tr) == len(streams) == 9
         n = flips = iflips = 0
-        first_flip_block = None
+        same = True
         for bi, blk in enumerate(tr):
             gs, gi = g[f'{key}.b{bi}.symbols'], g[f'{key}.b{bi}.indexes']
-            s = blk['symbols'].reshape(gs.shape)
-            i = blk['indexes'].reshape(gi.shape)
+            s, i = blk['symbols'].reshape(gs.shape), blk['indexes'].reshape(gi.shape)
             n += s.size
             f, fi = int((s != gs).sum()), int((i != gi).sum())
-            if (f or fi) and first_flip_block is None:
-                first_flip_block = bi
             flips += f; iflips += fi
-        report[key] = (flips, iflips, n, first_flip_block)
-        assert flips <= max(1, FLIP_BUDGET * n) * 50 or first_flip_block is not None, report
-        string = m.compress(im, lmb)
+            gold = g[f'{key}.b{bi}.string'].tobytes()
+            if f == 0 and fi == 0:
+                assert streams[bi] == gold, f'{case}: block {bi} stream differs although its symbols and indexes match'
+            else:
+                # a flipped scale index changes this block's stream legitimately; with the reference's value substituted at the
+                # flipped positions the coder must still reproduce the reference's bytes (a flip never waives the stream check)
+                same = False
+                fixed = rans_encode_streams(tables, [np.ascontiguousarray(gs.reshape(-1).astype(np.int32))],
+                                            [np.ascontiguousarray(gi.reshape(-1).astype(np.uint8))], 1)[0]
+                assert fixed == gold, f'{case}: block {bi} stream differs from the reference even with its symbols/indexes'
+        # reconstruction: the decoder fed with the GPU's own stream.  Symbols are required to be flip-free, and a scale-index flip
+        # does not change z, so this bound always applies.
         xhat = m.decompress(string)
         assert xhat.shape == (1, 3, h, w) and xhat.dtype == torch.float32
-        if flips == 0 and iflips == 0:
-            assert string == g[f'{key}.bitstream'].tobytes(), 'bitstream differs although all symbols/indexes match'
-            err = float((xhat.cpu() - torch.from_numpy(g[f'{key}.xhat'])).abs().max())
-            assert err <= 1e-4, (key, err)
-            report[key] += (err,)
-    print('golden parity report (flips, idx flips, n, first block[, max|dx|]):', report)
-    # the first (top) latent block sees no upstream flips: it must be exact everywhere
-    for lmb in g['lmbs'].tolist():
-        key = f'lmb{int(lmb)}'
-        tr = m.encode_trace(im, lmb)
+        err = float((xhat.cpu() - torch.from_numpy(g[f'{key}.xhat'])).abs().max())
+        # ... and the decoder fed with the REFERENCE's latents verbatim (independent of any encoder-side flip)
+        zs = [torch.from_numpy(g[f'{key}.b{bi}.symbols']).float() + torch.from_numpy(g[f'{key}.b{bi}.pm']) for bi in range(9)]
+        xz = m.conditional_sample(lmb, [z.cuda() for z in zs])
+        err_z = float((xz.cpu() - torch.from_numpy(g[f'{key}.xhat'])).abs().max())
+        parity_record(case, flips, iflips, n, max(err, err_z), same)
+        assert flips <= MAX_SYM_FLIPS and iflips <= MAX_IDX_FLIPS, (case, flips, iflips, n)
+        assert err <= 1e-4 and err_z <= 1e-4, (case, err, err_z)
+        if same:
+            assert string == g[f'{key}.bitstream'].tobytes()
+            clean += 1
+        # the first (top) latent block sees no upstream influence: exact everywhere
         assert np.array_equal(tr[0]['symbols'].reshape(-1), g[f'{key}.b0.symbols'].reshape(-1))
         assert np.array_equal(tr[0]['indexes'].reshape(-1), g[f'{key}.b0.indexes'].reshape(-1))
-    total = sum(v[0] + v[1] for v in report.values())
-    ntot = sum(v[2] for v in report.values())
-    assert total <= FLIP_BUDGET * ntot, report
+    assert clean >= len(lmbs) - 1, f'{tag} {prec}: only {clean} of {len(lmbs)} lambdas are flip-free'
 
 
 def test_round_trip_and_oracle(product_model, qarv_seeded_sd):
@@ -285,6 +306,23 @@ def test_progressive_decoding_matches_reference(product_model, golden_dir):
     assert nflip <= 2e-4 * ntot, (nflip, ntot)
     bits = nats[:, 0].cpu().numpy() / math.log(2)
     np.testing.assert_allclose(bits, g['bits'], rtol=2e-3, atol=8.0)
+
+
+def test_robust_decoding_matches_reference(product_model, golden_dir):
+    """The other decodings of scripts/qarv/robust-decoding.py:44-49 ('exclude', 'reverse', 'single') and an edited latent:
+    supplied latents are used verbatim (qarv/model.py:101-103) even where the block's prior mean differs from the one they
+    were quantised against."""
+    from test_oracle_golden import _robust_cases
+    m = product_model
+    g = np.load(os.path.join(golden_dir, 'qarv_base_64x64_robust.npz'))
+    lmb, (h, w) = float(g['lmb']), g['hw']
+    for name, lat in _robust_cases(g).items():
+        lat = [None if z is None else z.cuda() for z in lat]
+        x, used = m.conditional_sample(lmb, lat, bhw_repeat=(1, h // 64, w // 64), t=0, return_latents=True)
+        assert float((x.cpu() - torch.from_numpy(g[f'x.{name}'])).abs().max()) <= 1e-4, name
+        for z_in, z_used in zip(lat, used):
+            if z_in is not None:
+                assert torch.equal(z_in, z_used)
 
 
 def test_prior_sampling_statistics_and_determinism(product_model):

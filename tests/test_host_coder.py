@@ -134,24 +134,43 @@ def test_product_update_matches_reference_tables(golden_dir):
     assert q.dtype == np.int32 and q.flags['C_CONTIGUOUS'] and q.shape == (64, 249)
 
 
-@pytest.mark.parametrize('form', [0, 1])
-def test_native_table_builder_invariants(L, form):
-    """lvae_build_gaussian_tables (pure C, libm erff/erfcf): same lengths/offsets as the torch-built tables, valid CDF
-    rows, and entries within +-2 counts of them (libm vs torch erf differ by an ulp in places; see include/lvae_hip.h)."""
+@pytest.mark.parametrize('form,name', [(0, 'discretized_gaussian_tables'), (1, 'gaussian_conditional_tables')])
+def test_native_table_builder_equals_reference_tables(L, golden_dir, form, name):
+    """lvae_build_gaussian_tables (host C++, erf/erfc correctly rounded from double -- what DiscretizedGaussian.update() calls, on
+    whatever device the module lives) == the tables the REFERENCE's classes built (DiscretizedGaussian: erf form, QARV; stock
+    CompressAI-style GaussianConditional: erfc form, QRes), bit for bit; plus the CDF-row invariants of SURVEY.md 8(c)."""
     import scipy.stats
-    table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).numpy().astype(np.float32)
+    g = np.load(os.path.join(golden_dir, f'{name}.npz'))
+    table = np.ascontiguousarray(g['scale_table'].astype(np.float32))
     q = np.zeros((64, 256), dtype=np.int32); ln = np.zeros(64, dtype=np.int32); off = np.zeros(64, dtype=np.int32)
     mx = L.lvae_build_gaussian_tables(table.ctypes.data, 64, float(-scipy.stats.norm.ppf(0.5e-9)), form, q.ctypes.data, 256,
                                       ln.ctypes.data, off.ctypes.data)
     assert mx == 249
-    ref = DiscretizedGaussianOracle() if form == 0 else cs.GaussianConditional(None)
-    if form == 1:
-        ref.update_scale_table(torch.from_numpy(table))
-    else:
-        ref.update()
-    assert np.array_equal(ln, ref._cdf_length.numpy()) and np.array_equal(off, ref._offset.numpy())
-    rq = ref._quantized_cdf.numpy()
-    assert np.abs(q[:, :249] - rq).max() <= 2
+    assert np.array_equal(ln, g['cdf_length']) and np.array_equal(off, g['offset'])
+    assert np.array_equal(q[:, :249], g['quantized_cdf']) and not q[:, 249:].any()
     for i in range(64):
         row = q[i, :ln[i]]
         assert row[0] == 0 and row[-1] == 65536 and np.all(np.diff(row) >= 1)
+    # too small a row stride is refused, not overrun
+    assert L.lvae_build_gaussian_tables(table.ctypes.data, 64, float(-scipy.stats.norm.ppf(0.5e-9)), form, q.ctypes.data, 100,
+                                        ln.ctypes.data, off.ctypes.data) == -2
+
+
+def test_update_is_device_independent(golden_dir, monkeypatch):
+    """update() never evaluates the pmf with torch ops on the module's device (a GPU's erf may differ in the last ulp and a
+    stream must decode anywhere): the erfc-form module equals the reference table too, and `.to()` keeps the tables."""
+    from lvae.models.entropy_coding import DiscretizedGaussian
+    g = np.load(os.path.join(golden_dir, 'gaussian_conditional_tables.npz'))
+    dg = DiscretizedGaussian(cdf_form='erfc', scale_bound=0.11)
+    assert dg.update_scale_table(torch.from_numpy(g['scale_table']))
+    assert np.array_equal(dg._quantized_cdf.numpy(), g['quantized_cdf']) and np.array_equal(dg._offset.numpy(), g['offset'])
+    assert np.array_equal(dg._cdf_length.numpy(), g['cdf_length'])
+    q, l, o = dg.host_tables()
+    assert q.dtype == np.int32 and q.flags['C_CONTIGUOUS'] and np.array_equal(q, g['quantized_cdf'])
+    assert not dg.update_scale_table(torch.from_numpy(g['scale_table']) * 2)       # tables exist: no-op unless forced
+    def boom(*a, **k):
+        raise AssertionError('update() must not evaluate the pmf with torch ops')
+    monkeypatch.setattr(torch, 'erf', boom); monkeypatch.setattr(torch, 'erfc', boom)
+    dg2 = DiscretizedGaussian(cdf_form='erf')
+    dg2.update()
+    assert dg2._quantized_cdf.shape == (64, 249)

@@ -126,6 +126,32 @@ def test_progressive_decoding_t0(golden_dir, oracle_model):
     np.testing.assert_allclose(x.numpy(), g['x_uncond_t0'], rtol=0, atol=2e-5)
 
 
+def _robust_cases(g):
+    """latent lists of tests/golden/qarv_base_64x64_robust.npz (make_golden.py::golden_robust)."""
+    zs = [torch.from_numpy(g[f'z{i}']) for i in range(9)]
+    cases = {}
+    for a in (0, 4, 8):
+        cases[f'exclude{a}'] = [None if i == a else z for i, z in enumerate(zs)]
+    for a in (2, 6):
+        cases[f'reverse{a}'] = [None if i < a else z for i, z in enumerate(zs)]
+    for a in (0, 3, 8):
+        cases[f'single{a}'] = [z if i == a else None for i, z in enumerate(zs)]
+    ed = list(zs)
+    ed[1], ed[5] = torch.from_numpy(g['edited.z1']), torch.from_numpy(g['edited.z5'])
+    cases['edited'] = ed
+    return cases
+
+
+def test_robust_decoding_uses_latents_verbatim(golden_dir, oracle_model):
+    """'exclude' / 'reverse' / 'single' decodings of scripts/qarv/robust-decoding.py:44-49 and an edited latent: a supplied latent
+    is used as it is (qarv/model.py:101-103) although its block's prior mean has changed."""
+    g = np.load(os.path.join(golden_dir, 'qarv_base_64x64_robust.npz'))
+    lmb, (h, w) = float(g['lmb']), g['hw']
+    for name, lat in _robust_cases(g).items():
+        x = oracle_model.decode_from_latents(lmb, lat, bhw_repeat=(1, h // 64, w // 64))
+        np.testing.assert_allclose(x.numpy(), g[f'x.{name}'], rtol=0, atol=2e-5, err_msg=name)
+
+
 def test_imcoding_evaluate_contract(golden_dir, oracle_model, tmp_path):
     """lvae/evaluation.py:15-67 semantics: bpp over ORIGINAL pixels incl. 4-byte (h,w) header; PSNR on the
     un-rounded float reconstruction; mean of per-image values; ragged sizes padded (coding.py:73-91)."""

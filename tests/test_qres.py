@@ -74,6 +74,42 @@ def test_oracle_matches_reference(golden_dir, oracle, tag, seed):
     np.testing.assert_allclose(xhat.numpy(), g['xhat'], rtol=0, atol=1e-4 if flips == 0 else 5e-2)
 
 
+# Absolute per-case ceilings on the MI355X: no symbol flip, at most two scale indexes (qres34m: 0-2 observed).
+MAX_SYM_FLIPS, MAX_IDX_FLIPS = 0, 2
+
+
+def _hip_golden_case(product, g, im, case, n_blocks=12):
+    """HIP path vs one reference golden: per-block symbols / scale indexes under absolute ceilings, every block's rANS stream
+    byte-identical (for a block with a flipped scale index: after substituting the reference's value, through the same coder),
+    reconstruction within 1e-4 -- never waived.  One row goes to the parity report (tests/conftest.py)."""
+    from conftest import parity_record
+    from lvae.models.entropy_coding import rans_encode_streams
+    tr = product.encode_trace(im)
+    obj = product.compress(im)
+    assert len(tr) == n_blocks and len(obj) == n_blocks + 1 and tuple(obj[-1]) == tuple(g['smallest'].tolist())
+    tables = product._dg().host_tables()
+    n = flips = iflips = 0
+    same = True
+    for bi, blk in enumerate(tr):
+        gs, gi = g[f'b{bi}.symbols'].reshape(-1), g[f'b{bi}.indexes'].reshape(-1)
+        f, fi = int((blk['symbols'].reshape(-1) != gs).sum()), int((blk['indexes'].reshape(-1) != gi).sum())
+        n += gs.size; flips += f; iflips += fi
+        gold = g[f'b{bi}.string'].tobytes()
+        if f == 0 and fi == 0:
+            assert obj[bi][0] == gold, f'{case}: block {bi} stream differs although its symbols and indexes match'
+        else:
+            same = False
+            fixed = rans_encode_streams(tables, [np.ascontiguousarray(gs.astype(np.int32))], [np.ascontiguousarray(gi.astype(np.uint8))], 1)[0]
+            assert fixed == gold, f'{case}: block {bi}'
+    xhat = product.decompress(obj)
+    err = float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max())
+    parity_record(case, flips, iflips, n, err, same)
+    assert np.array_equal(tr[0]['symbols'].reshape(-1), g['b0.symbols'].reshape(-1))
+    assert flips <= MAX_SYM_FLIPS and iflips <= MAX_IDX_FLIPS, (case, flips, iflips, n)
+    assert err <= 1e-4, (case, err)
+    return flips + iflips
+
+
 @pytest.fixture(scope='module')
 def product(qres_sd):
     import lvae
@@ -92,23 +128,7 @@ def product(qres_sd):
 def test_hip_matches_reference(golden_dir, product, tag, seed):
     g = np.load(os.path.join(golden_dir, f'qres34m_{tag}.npz'))
     h, w = g['hw'].tolist()
-    im = _img(h, w, seed).cuda()
-    tr = product.encode_trace(im)
-    n = flips = 0
-    for bi, blk in enumerate(tr):
-        n += blk['symbols'].size
-        flips += int((blk['symbols'].reshape(-1) != g[f'b{bi}.symbols'].reshape(-1)).sum())
-        flips += int((blk['indexes'].reshape(-1) != g[f'b{bi}.indexes'].reshape(-1)).sum())
-    print(f'qres34m {tag}: {flips} flips of {n}')
-    assert np.array_equal(tr[0]['symbols'].reshape(-1), g['b0.symbols'].reshape(-1))
-    assert flips <= FLIP_BUDGET * n
-    obj = product.compress(im)
-    assert tuple(obj[-1]) == tuple(g['smallest'].tolist()) and len(obj) == 13
-    xhat = product.decompress(obj)
-    if flips == 0:
-        for bi in range(12):
-            assert obj[bi][0] == g[f'b{bi}.string'].tobytes()
-        assert float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max()) <= 1e-4
+    _hip_golden_case(product, g, _img(h, w, seed).cuda(), f'qres34m {tag}')
 
 
 @pytest.mark.gpu
@@ -197,7 +217,11 @@ def test_lossless_hip_matches_reference_and_is_lossless(golden_dir, lossless_pro
     n = sym.size
     flips = int((sym != g['out.symbols']).sum()) + int((idx != g['out.indexes']).sum())
     print(f'qres34m_lossless: latent strings identical: {lat_same}; pixel stream flips {flips} of {n}; max|dpm| {np.abs(pm - g["out.pm"]).max()}')
-    assert flips <= (2e-4 if lat_same else 0.05) * n
+    from conftest import parity_record
+    parity_record('qres34m_lossless 64x128 (12 latent streams + per-pixel stream)', int((sym != g['out.symbols']).sum()),
+                  int((idx != g['out.indexes']).sum()), n, 0.0, lat_same and flips == 0)
+    # absolute ceilings (MI355X today: latent strings byte-identical, 2 of 24 576 per-pixel elements off by one table row / unit)
+    assert lat_same and flips <= 4, (lat_same, flips, n)
     if lat_same and flips == 0:
         assert obj[-1][0] == g['out.string'].tobytes()
         assert len(pickle.dumps(obj + [(h, w)])) == int(g['pickle_bytes'])
@@ -271,21 +295,7 @@ def test_qres17m_hip_matches_reference(golden_dir, q17_product):
     g = np.load(os.path.join(golden_dir, 'qres17m_64x128.npz'))
     h, w = g['hw'].tolist()
     im = _img(h, w, int(g['img_seed'])).cuda()
-    tr = m.encode_trace(im)
-    n = flips = 0
-    for bi, blk in enumerate(tr):
-        n += blk['symbols'].size
-        flips += int((blk['symbols'].reshape(-1) != g[f'b{bi}.symbols'].reshape(-1)).sum())
-        flips += int((blk['indexes'].reshape(-1) != g[f'b{bi}.indexes'].reshape(-1)).sum())
-    print(f'qres17m: {flips} flips of {n}')
-    assert len(tr) == 12 and flips <= FLIP_BUDGET * n
-    obj = m.compress(im)
-    assert tuple(obj[-1]) == tuple(g['smallest'].tolist()) and len(obj) == 13
-    xhat = m.decompress(obj)
-    if flips == 0:
-        for bi in range(12):
-            assert obj[bi][0] == g[f'b{bi}.string'].tobytes()
-        assert float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max()) <= 1e-4
+    _hip_golden_case(m, g, im, 'qres17m 64x128')
     ims = torch.cat([_img(128, 64, s) for s in (1, 2, 3)], 0).cuda()
     objs = m.compress_batch(ims)
     assert objs[2] == m.compress(ims[2:3])
