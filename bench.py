@@ -141,8 +141,16 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     model, sd = build_model(dev)
-    # one rank per GPU shares the node's host cores: give each rank its slice for the rANS coder threads
-    model.coder_threads = max(8, (os.cpu_count() or 64) // max(1, world))
+    # one rank per GPU shares the node's host cores: every rank's threads (launch threads, rANS coder pool) stay on its slice of
+    # the cores of its GPU's NUMA node (skipped when the node topology cannot be read or looks skewed), pool sized to the slice
+    ncpu = None
+    if world > 1 and os.environ.get('LVAE_BENCH_SINGLE_GPU_TEST') != '1':
+        from lvae.utils.numa import pin_ranks_collectively
+        ncpu = pin_ranks_collectively(local_rank, dist, local_rank, world)
+    if ncpu:
+        model.coder_threads = max(4, ncpu)
+    else:
+        model.coder_threads = max(8, (os.cpu_count() or 64) // max(1, world))
     model.set_gemm_precision(args.precision)
     ims = synth_batch(B, H, W, rank).to(dev)
 

@@ -56,8 +56,63 @@ def imcoding_evaluate(model, dataset, progress=False):
 
 
 def shard_paths(img_paths, rank, world):
-    """Rank r of W codes sorted(img_paths)[r::W] (SURVEY.md 8(e))."""
+    """Rank r of W codes sorted(img_paths)[r::W] (SURVEY.md 8(e)) -- the partition for same-size sets."""
     return img_paths[rank::world]
+
+
+def padded_pixels(path, div=64):
+    """Pixel count of an image after padding to multiples of `div` (what the codec actually processes); header read only."""
+    from PIL import Image
+    with Image.open(path) as img:
+        h, w = img.height, img.width
+    return (div * math.ceil(h / div)) * (div * math.ceil(w / div)), (div * math.ceil(h / div), div * math.ceil(w / div))
+
+
+def lpt_partition(costs, world):
+    """Longest-processing-time-first partition of items with the given costs over `world` ranks (mixed-size sets
+    such as CLIC-2022, where rank::world leaves the ranks with the portrait/landscape 2048-wide images late).  Deterministic on
+    every rank: items sorted by (-cost, index), each given to the least-loaded rank (ties -> lowest rank).  Returns a list of
+    `world` index lists, each in ascending index order."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads, parts = [0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(p) for p in parts]
+
+
+def batch_same_size(indices, shapes, max_batch=8, max_pixels=8 * 512 * 768 * 4):
+    """Group a rank's images by padded size into batches (<= max_batch images, <= max_pixels padded pixels in total): the GPU part
+    of a batch runs batched and its rANS streams are coded by parallel host threads, instead of one image at a time."""
+    groups, out = {}, []
+    for i in indices:
+        groups.setdefault(shapes[i], []).append(i)
+    for shape, idxs in groups.items():
+        per = max(1, min(max_batch, max_pixels // (shape[0] * shape[1])))
+        for o in range(0, len(idxs), per):
+            out.append(idxs[o:o + per])
+    out.sort(key=lambda b: b[0])
+    return out
+
+
+def _eval_batch(model, paths, tmp_bits_dir, tag=''):
+    """_eval_one for a batch of same-padded-size images through the model's batched file API (bit-identical per image)."""
+    from PIL import Image
+    if len(paths) == 1 or not hasattr(model, 'compress_files'):
+        return [_eval_one(model, p, tmp_bits_dir, tag) for p in paths]
+    bits = [tmp_bits_dir / f'{p.stem}{tag}.{k}.bits' for k, p in enumerate(paths)]
+    model.compress_files(paths, bits)
+    fakes = model.decompress_files(bits)
+    out = []
+    for p, b, fake in zip(paths, bits, fakes):
+        num_bits = b.stat().st_size * 8
+        b.unlink()
+        real = pil_to_tensor01(Image.open(p))
+        mse = (real - fake.squeeze(0).cpu()).square().mean().item()
+        out.append({'bpp': float(num_bits / float(real.shape[1] * real.shape[2])), 'mse': float(mse),
+                    'psnr': float(-10 * math.log10(mse))})
+    return out
 
 
 def gather_stats(local, world, device=None):
@@ -79,16 +134,24 @@ def gather_stats(local, world, device=None):
 
 
 @torch.no_grad()
-def imcoding_evaluate_sharded(model, dataset):
-    """Same result as imcoding_evaluate, with the image list sharded over torch.distributed ranks."""
+def imcoding_evaluate_sharded(model, dataset, partition='lpt', max_batch=8):
+    """Same result as imcoding_evaluate (to the last bit: per-image values do not depend on batching, means are formed in image
+    order), with the image list sharded over torch.distributed ranks: LPT by padded pixel count (`partition='stride'`:
+    rank::world), and inside a rank same-size images coded as batches of up to `max_batch`."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     img_paths = _list_images(dataset)
     tmp_bits_dir = Path(gettempdir())
+    meta = [padded_pixels(p, getattr(model, 'max_stride', 64)) for p in img_paths]
+    if partition == 'lpt':
+        mine = lpt_partition([m[0] for m in meta], world)[rank]
+    else:
+        mine = list(range(rank, len(img_paths), world))
     local = []
-    for idx in range(rank, len(img_paths), world):
-        s = _eval_one(model, img_paths[idx], tmp_bits_dir, tag=f'.r{rank}')
-        local.append([float(idx), s['bpp'], s['mse'], s['psnr']])
+    for batch in batch_same_size(mine, [m[1] for m in meta], max_batch=max_batch):
+        stats = _eval_batch(model, [img_paths[i] for i in batch], tmp_bits_dir, tag=f'.r{rank}')
+        for idx, s in zip(batch, stats):
+            local.append([float(idx), s['bpp'], s['mse'], s['psnr']])
     dev = next(model.parameters()).device
     rows = gather_stats(local, world, dev if dist.get_backend() == 'nccl' else None)
     assert rows.shape[0] == len(img_paths)

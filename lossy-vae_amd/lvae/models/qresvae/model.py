@@ -635,6 +635,30 @@ class HierarchicalVAE(CodecBase):
         return self.decompress(obj)[:, :, :img_h, :img_w]
 
     @torch.no_grad()
+    def compress_files(self, img_paths, output_paths):
+        """Batched compress_file (same padded size): one compress_batch call; files identical to compress_file's."""
+        from PIL import Image
+        imgs = [Image.open(p) for p in img_paths]
+        ims = [coding.pil_to_tensor01(coding.pad_divisible_by(img, div=self.max_stride)) for img in imgs]
+        assert all(t.shape == ims[0].shape for t in ims), 'compress_files: padded sizes differ'
+        objs = self.compress_batch(torch.stack(ims).to(device=self._dummy.device))
+        for img, obj, out in zip(imgs, objs, output_paths):
+            obj.append((img.height, img.width))
+            with open(out, 'wb') as f:
+                pickle.dump(obj, file=f)
+
+    @torch.no_grad()
+    def decompress_files(self, bits_paths):
+        objs, sizes = [], []
+        for p in bits_paths:
+            with open(p, 'rb') as f:
+                obj = pickle.load(file=f)
+            sizes.append(obj.pop())
+            objs.append(obj)
+        out = self.decompress_batch(objs)
+        return [out[i:i + 1, :, :h, :w] for i, (h, w) in enumerate(sizes)]
+
+    @torch.no_grad()
     @on_model_device
     def encode_trace(self, im):
         B, _, H, W = im.shape

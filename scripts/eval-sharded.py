@@ -33,9 +33,13 @@ def main():
     args = ap.parse_args()
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+    if os.environ.get('LVAE_SINGLE_GPU_TEST') == '1':      # rehearsal of the N > 1 path on a 1-GPU box: every rank on cuda:0 (use --backend gloo)
+        local = 0
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dist.init_process_group(args.backend, rank=rank, world_size=world)
+    from lvae.utils.numa import pin_ranks_collectively
+    ncpu = None if os.environ.get('LVAE_SINGLE_GPU_TEST') == '1' else pin_ranks_collectively(local, dist, local, world)
     kwargs = eval(f'dict({args.model_args})')
     dataset = args.dataset_name
     if args.synthetic:
@@ -60,6 +64,7 @@ def main():
         model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.compress_mode()
+    model.coder_threads = max(4, ncpu or (os.cpu_count() or 8) // max(1, world))     # coder / launch threads on the GPU's socket
     start, end = args.lmb_range or getattr(model, 'lmb_range', (0, 0))
     lambdas = torch.linspace(math.log(start), math.log(end), steps=args.steps).exp().tolist() if hasattr(model, 'default_lmb') else [None]
     for lmb in lambdas:

@@ -68,3 +68,30 @@ def test_sharded_eval_equals_single(tmp_path):
     assert res == single, (res, single)
     paths = list(range(7))
     assert shard_paths(paths, 0, 2) == [0, 2, 4, 6] and shard_paths(paths, 1, 2) == [1, 3, 5]
+
+
+def test_lpt_partition_and_same_size_batches():
+    """SURVEY.md 8(e) host side: LPT by padded pixel count (every image exactly once, makespan <= 4/3 OPT + deterministic), batches
+    of equal padded size bounded by count and pixels."""
+    from lvae.evaluation import batch_same_size, lpt_partition
+    clic = [1408 * 2048, 2048 * 1408, 1152 * 2048, 2048 * 1536] * 7 + [1408 * 2048, 2048 * 1408]       # 30 images, CLIC-like
+    parts = lpt_partition(clic, 8)
+    assert sorted(i for p in parts for i in p) == list(range(30)) and all(p == sorted(p) for p in parts)
+    loads = [sum(clic[i] for i in p) for p in parts]
+    stride = [sum(clic[i] for i in range(r, 30, 8)) for r in range(8)]
+    assert max(loads) <= max(stride) and max(loads) <= 4 / 3 * (sum(clic) / 8) + max(clic) / 3
+    assert lpt_partition(clic, 8) == parts and lpt_partition([5, 5, 5], 1) == [[0, 1, 2]] and lpt_partition([], 2) == [[], []]
+    shapes = [(1408, 2048), (2048, 1408), (1408, 2048), (64, 64), (1408, 2048), (64, 64)] + [(1408, 2048)] * 5
+    b = batch_same_size(list(range(11)), shapes, max_batch=8, max_pixels=4 * 1408 * 2048)
+    assert sorted(i for g in b for i in g) == list(range(11))
+    assert all(len({shapes[i] for i in g}) == 1 and len(g) <= 8 and len(g) * shapes[g[0]][0] * shapes[g[0]][1] <= 4 * 1408 * 2048 for g in b)
+    assert [0, 2, 4, 6] in b and [3, 5] in b and [1] in b
+
+
+def test_numa_cpulist_parser_and_noop_without_topology():
+    from lvae.utils import numa
+    assert numa._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and numa._parse_cpulist('') == []
+    before = os.sched_getaffinity(0)
+    assert numa.pin_rank(0) is None or isinstance(numa.pin_rank(0), int)       # no GPU here: unreadable topology -> no-op
+    if not torch.cuda.is_available():
+        assert os.sched_getaffinity(0) == before
