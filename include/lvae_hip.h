@@ -131,6 +131,10 @@ typedef struct {
                                              heads).  Row-major store only, N % 4 == 0.  The host must choose S independently of
                                              the batch size (per-image rows), so that batched and single-image calls agree */
     float* ws;                            /* split-K workspace, S*M*N floats (unused when ksplit <= 1) */
+    int* cnt;                             /* split-K arrival counters, one int per output tile (>= ceil(M/64)*ceil(N/32) entries covers
+                                             every tile shape), ZERO before the first launch; each launch leaves them zero again.
+                                             Non-NULL: the last slice workgroup of a tile to arrive reduces the S slabs in slice order
+                                             inside the GEMM launch (no second kernel; same bits).  NULL: separate reduce launch */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */

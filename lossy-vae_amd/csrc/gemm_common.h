@@ -11,6 +11,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 
 
@@ -55,7 +56,10 @@ struct Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <class C>
+// SLAB = true: split-K partial sums going to the workspace with WRITE-THROUGH (sc1) 16-B buffer stores, so that the in-kernel
+// reduction needs no agent-scope release (a buffer_wbl2 writes back every dirty line of the XCD's L2, also those of kernels
+// running beside this one on another stream: measured -14 % end to end): cdna_hip_programming.md Guideline 16, form R1.
+template <class C, bool SLAB = false>
 __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&acc)[C::TM][C::TN], int m0, int n0, int wave_m,
                                               int wave_n, int li, int lh) {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -119,7 +123,14 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
                             const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
                             o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
                         }
-                        *(f32x4*)(d.out + obase + ccol4[b]) = o;
+                        if (SLAB) {
+                            const long bytes = (long)d.M * d.N * 4;
+                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                                (void*)d.out, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs, (int)((obase + ccol4[b]) * 4), 0, 16);
+                        } else {
+                            *(f32x4*)(d.out + obase + ccol4[b]) = o;
+                        }
                     }
                 }
             }
@@ -177,17 +188,79 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
     }
 }
 
+// Split-K tail: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias) for the BM x BN tile at (m0, n0): 4 columns per
+// thread, 16-B accesses.  Shared by the in-kernel reduction (the tile's last-arriving slice workgroup) and by the stand-alone reduce
+// kernel (d.cnt == NULL): same operations in the same order, hence the same bits.
+__device__ __forceinline__ void splitk_reduce_chunk(const lvae_gemm_desc& d, int S, long m, int c) {
+    const long plane = (long)d.M * d.N;
+    const float* w = d.ws + m * d.N + c;
+    f32x4 v = *(const f32x4*)w;
+    for (int s = 1; s < S; ++s) {
+        const f32x4 p = *(const f32x4*)(w + s * plane);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    if (d.bias) { const f32x4 b = *(const f32x4*)(d.bias + c); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (d.epi == LVAE_EPI_BIAS_GELU) {
+        float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        gelu_erf2(a0, a1); gelu_erf2(a2, a3);
+        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+    } else if (d.epi == LVAE_EPI_GAMMA_RES) {
+        const f32x4 g = *(const f32x4*)(d.gamma + c), r = *(const f32x4*)(d.res + m * d.ldres + c);
+        v[0] = r[0] + g[0] * v[0]; v[1] = r[1] + g[1] * v[1]; v[2] = r[2] + g[2] * v[2]; v[3] = r[3] + g[3] * v[3];
+    } else if (d.epi == LVAE_EPI_RES) {
+        const f32x4 r = *(const f32x4*)(d.res + m * d.ldres + c);
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    *(f32x4*)(d.out + m * d.ldo + c) = v;
+}
+
 // Every GEMM kernel ends here.  gridDim.y = number of K slices: with split-K the raw partial sums of slice blockIdx.y go to its
-// workspace plane (row-major, no bias / activation / residual); splitk_reduce_kernel (gemm_f32.hip) finishes the job.
+// workspace plane (row-major, no bias / activation / residual).  Then either a second kernel finishes the job (d.cnt == NULL:
+// splitk_reduce_kernel, gemm_f32.hip) or -- the default -- the LAST slice workgroup of the tile to arrive does it in place
+// (d.cnt = one zeroed arrival counter per tile): write-through (sc1) slab stores -> every wave drains its stores -> workgroup
+// barrier -> one lane: ticket = relaxed agent-scope atomic add on the tile's counter; the workgroup that draws S-1 acquires (agent scope), re-reads
+// ALL S slabs -- its own included -- in slice order and applies the epilogue, then zeroes the counter for the next launch.
+// The sum order is fixed (slice 0, 1, ..., S-1) whoever arrives last, so the result is deterministic and equal to the two-kernel
+// form; nothing depends on dispatch order or workgroup -> XCD placement (cdna_hip_programming.md Guideline 16, counter form).
+// `lds` is the kernel's dynamic LDS (free after the main loop: the broadcast word lives there, not in a second __shared__ object).
 template <class C>
 __device__ __forceinline__ void gemm_finish(const lvae_gemm_desc& d, f32x16 (&acc)[C::TM][C::TN], int m0, int n0, int wave_m,
-                                            int wave_n, int li, int lh) {
+                                            int wave_n, int li, int lh, void* lds, int tile) {
     lvae_gemm_desc p = d;
-    if (gridDim.y > 1) {
+    const int S = (int)gridDim.y;
+    if (S > 1) {
         p.out = d.ws + (long)blockIdx.y * d.M * d.N;
         p.ldo = d.N; p.bias = nullptr; p.epi = LVAE_EPI_BIAS; p.store = LVAE_ST_ROWMAJOR; p.res = nullptr; p.ldres = 0;
     }
-    gemm_epilogue<C>(p, acc, m0, n0, wave_m, wave_n, li, lh);
+    if (!(S > 1 && d.cnt)) {
+        gemm_epilogue<C>(p, acc, m0, n0, wave_m, wave_n, li, lh);
+        return;
+    }
+    {
+        gemm_epilogue<C, true>(p, acc, m0, n0, wave_m, wave_n, li, lh);     // write-through slab stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its slab stores
+        __syncthreads();
+        volatile int* last = (volatile int*)lds;
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(d.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = old == S - 1;
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(d.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+            *last = is_last;
+        }
+        __syncthreads();
+        if (*last) {
+            const int rows = (d.M - m0) < C::BM ? (d.M - m0) : C::BM;
+            const int cols = (d.N - n0) < C::BN ? (d.N - n0) : C::BN;       // N % 4 == 0 (checked on the host)
+            const int c4n = cols >> 2;
+            for (int e = threadIdx.x; e < rows * c4n; e += C::NT) {
+                const int r = e / c4n, c4 = e - r * c4n;
+                splitk_reduce_chunk(d, S, (long)(m0 + r), n0 + 4 * c4);
+            }
+        }
+    }
 }
 
 }  // namespace

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(const lvae_gemm_desc d, 
 #else
 #define TRACE_END() do {} while (0)
 #endif
-    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
     TRACE_END();
 }
 
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const lvae_gemm_des
             __syncthreads();
         }
     }
-    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 }
 
 // ---------------------------------------------------------------- fp32-accurate split variant ("bf16x3")
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(const lvae_gemm_desc 
             __syncthreads();
         }
     }
-    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 }
 
 inline int ksp(const lvae_gemm_desc* d) { return d->ksplit > 1 ? d->ksplit : 1; }
@@ -645,33 +645,13 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     }
 }
 
-// split-K second pass: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias), 4 columns per thread, 16-B accesses
+// split-K second pass (d.cnt == NULL only): one thread per 16-B chunk of the whole output
 __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = d.N >> 2;
     if (e >= (long)d.M * n4) return;
     const long m = e / n4;
-    const int c = (int)(e - m * n4) * 4;
-    const long plane = (long)d.M * d.N;
-    const float* w = d.ws + m * d.N + c;
-    f32x4 v = *(const f32x4*)w;
-    for (int s = 1; s < S; ++s) {
-        const f32x4 p = *(const f32x4*)(w + s * plane);
-        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
-    }
-    if (d.bias) { const f32x4 b = *(const f32x4*)(d.bias + c); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
-    if (d.epi == LVAE_EPI_BIAS_GELU) {
-        float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-        gelu_erf2(a0, a1); gelu_erf2(a2, a3);
-        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
-    } else if (d.epi == LVAE_EPI_GAMMA_RES) {
-        const f32x4 g = *(const f32x4*)(d.gamma + c), r = *(const f32x4*)(d.res + m * d.ldres + c);
-        v[0] = r[0] + g[0] * v[0]; v[1] = r[1] + g[1] * v[1]; v[2] = r[2] + g[2] * v[2]; v[3] = r[3] + g[3] * v[3];
-    } else if (d.epi == LVAE_EPI_RES) {
-        const f32x4 r = *(const f32x4*)(d.res + m * d.ldres + c);
-        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-    }
-    *(f32x4*)(d.out + m * d.ldo + c) = v;
+    splitk_reduce_chunk(d, S, m, (int)(e - m * n4) * 4);
 }
 
 }  // namespace
@@ -704,8 +684,16 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
         if (!d->ws || d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S) ||
             (d->prec == 1 && d->K % (64 * S)))
             return -22;
+        // In-kernel reduction only when no 128-B line of the workspace can hold columns of two different tiles (N % 32 == 0, or one
+        // n-tile): a tile's reducer acquires at agent scope, which drops its CU's L1 but not lines its XCD's L2 fetched earlier in
+        // this launch for a NEIGHBOURING tile's reduction.
+        if (d->cnt && !((d->N & 31) == 0 || d->N <= 32)) {
+            lvae_gemm_desc d2 = *d;
+            d2.cnt = nullptr;
+            return lvae_gemm_f32(&d2, stream);
+        }
         const int rc = gemm_dispatch(d, st, x3v2, x3v2_tn);
-        if (rc) return rc;
+        if (rc || d->cnt) return rc;                                  // cnt: reduced in place by each tile's last-arriving slice
         const long n = (long)d->M * (d->N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d, S);
         return (int)hipGetLastError();

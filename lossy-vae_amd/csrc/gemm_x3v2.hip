@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3w8_kernel(const lvae_gemm_desc 
         }
         __syncthreads();
     }
-    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 }
 
 template <bool AGELU>
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
 #ifdef LVAE_X3V2_TRACE
     if (tracing) lvae_trace_buf[121] = __builtin_readcyclecounter();
 #endif
-    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh);
+    gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 #ifdef LVAE_X3V2_TRACE
     if (tracing) lvae_trace_buf[122] = __builtin_readcyclecounter();
 #endif

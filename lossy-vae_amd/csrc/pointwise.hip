@@ -792,5 +792,5 @@ extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 9; }
+extern "C" int lvae_abi_version(void) { return 10; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

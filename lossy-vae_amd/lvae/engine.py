@@ -59,6 +59,7 @@ def autotune_gemm(lib, d, stream_ptr, device):
 # decoder priors must agree bit for bit), so they are compile-time constants of the package, not environment knobs.
 KSPLIT_MAX_TILES_PER_IMAGE = 96       # only the few-tile layers (stride-16..64 MLPs, 3x3 heads) are split
 KSPLIT_TARGET_WORKGROUPS = 256        # slices x tiles-per-image stays within one workgroup per CU
+INKERNEL_REDUCE_MAX_BYTES = 48 * 1024  # slabs of one tile (S x tile bytes) up to which the last-arriver reduction is used
 
 
 def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
@@ -167,6 +168,18 @@ class Plan:
             ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
         if ksplit > 1:
             d.ksplit, d.ws = ksplit, self.buf('splitk_ws', ksplit * M * N).data_ptr()
+            # In-kernel slice reduction (lvae_gemm_desc.cnt: a tile's last-arriving slice workgroup sums the S slabs in place of the
+            # second launch) is taken only when the slabs of one tile are small: the last arriver reads S x tile bytes ALONE at the
+            # cross-XCD rate (~65 GB/s per workgroup), so with the 128 x 128..192 tiles of the MLP layers (64-98 KB x S) it costs more
+            # than the reduce launch it removes (measured on MI355X: 105 -> 100 Mpixels/s at B = 8, 12.1 -> 13.3 ms at B = 1).
+            if ksplit * 128 * min(N, 192) * 4 <= INKERNEL_REDUCE_MAX_BYTES:
+                n_cnt = ((M + 63) // 64) * ((N + 31) // 32)
+                cnt = self.bufs.get('splitk_cnt')
+                if cnt is None or cnt.numel() < n_cnt:
+                    if cnt is not None:
+                        self.keep.append(cnt)
+                    cnt = self.bufs['splitk_cnt'] = torch.zeros(max(4096, n_cnt), dtype=torch.int32, device=self.device)
+                d.cnt = cnt.data_ptr()
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             d.cfg = autotune_gemm(self.lib, d, sp, self.device)

@@ -359,20 +359,28 @@ def test_gemm_split_k(M, N, K, S, epi, a_mode, prec):
     bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).cuda()
 
-    def run(m_rows, ksplit):
+    cnt = torch.zeros(4096, dtype=torch.int32, device='cuda')       # arrival counters of the in-kernel reduction (zero at rest)
+
+    def run(m_rows, ksplit, in_kernel=True, reps=1):
         out = torch.full((m_rows, N), float('nan'), device='cuda')
-        ws = torch.empty(max(1, ksplit) * m_rows * N, device='cuda')
+        ws = torch.full((max(1, ksplit) * m_rows * N,), float('nan'), device='cuda')
         d = _native.GemmDesc()
         d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = A.data_ptr(), Cin, Cin, Wt.data_ptr(), W3.data_ptr(), K
         d.bias, d.gamma, d.res, d.ldres, d.out, d.ldo = bias.data_ptr(), gamma.data_ptr(), res.data_ptr(), N, out.data_ptr(), N
         d.M, d.N, d.K, d.epi, d.prec, d.a_mode, d.H, d.W = m_rows, N, K, epi, prec, a_mode, Hh, Ww
         d.ksplit, d.ws = ksplit, ws.data_ptr()
-        assert L.lvae_gemm_f32(ctypes.byref(d), st) == 0
+        d.cnt = cnt.data_ptr() if (in_kernel and ksplit > 1) else None
+        for _ in range(reps):
+            assert L.lvae_gemm_f32(ctypes.byref(d), st) == 0
         torch.cuda.synchronize()
         return out
 
-    o1, oS, oS2 = run(M, 1), run(M, S), run(M, S)
+    o1, oS, oS2 = run(M, 1), run(M, S), run(M, S, in_kernel=False)
+    # the in-kernel reduction (a tile's last-arriving slice workgroup sums the slabs in slice order) == the two-kernel form, bit for
+    # bit, and leaves its arrival counters zero for the next launch; repeated back-to-back launches reuse workspace and counters
     assert torch.equal(oS, oS2)
+    assert int(cnt.abs().sum().item()) == 0
+    assert torch.equal(run(M, S, reps=5), oS) and int(cnt.abs().sum().item()) == 0
     if a_mode == 0:
         ref = A.double() @ Wt.double().t() + bias.double()
         ref = {0: ref, 1: torch.nn.functional.gelu(ref), 2: res.double() + gamma.double() * ref, 3: res.double() + ref}[epi]
@@ -382,6 +390,59 @@ def test_gemm_split_k(M, N, K, S, epi, a_mode, prec):
         assert torch.equal(run(half, S), oS[:half])          # M-independence (rows of a smaller call)
     else:
         assert float((oS - o1).abs().max()) <= 2e-5 * max(1.0, float(o1.abs().max()))
+
+
+def test_gemm_split_k_in_kernel_reduction_under_load():
+    """The hand-off inside the launch (slab stores -> agent-scope release -> ticket -> last arriver's agent-scope acquire -> slab
+    loads) must hold under UNEVEN load with the consumer's caches warm (MI355X_MICROARCH.md, visibility rules): many different
+    shapes back to back on two streams sharing the GPU, every output word compared with the two-kernel form."""
+    import ctypes
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    L = _native.lib()
+    g = torch.Generator().manual_seed(7)
+    cases = []
+    for (M, N, K, S) in [(3072, 512, 1024, 2), (768, 1024, 512, 4), (3072, 512, 1536, 4), (96, 512, 2048, 16), (1536, 384, 768, 2),
+                         (384, 512, 1024, 8), (12288, 96, 3456, 4)]:
+        A = torch.randn(M, K, generator=g).cuda()
+        Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        cases.append(dict(M=M, N=N, K=K, S=S, A=A, Wt=Wt, W3=pack_bf16x3(Wt), bias=torch.randn(N, generator=g).cuda(),
+                          res=torch.randn(M, N, generator=g).cuda(), gamma=torch.rand(N, generator=g).cuda()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def launch(c, out, ws, cnt, stream, in_kernel):
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = c['A'].data_ptr(), c['K'], c['K'], c['Wt'].data_ptr(), c['W3'].data_ptr(), c['K']
+        d.bias, d.gamma, d.res, d.ldres, d.out, d.ldo = c['bias'].data_ptr(), c['gamma'].data_ptr(), c['res'].data_ptr(), c['N'], out.data_ptr(), c['N']
+        d.M, d.N, d.K, d.epi, d.prec = c['M'], c['N'], c['K'], 2, 2
+        d.ksplit, d.ws, d.cnt = c['S'], ws.data_ptr(), (cnt.data_ptr() if in_kernel else None)
+        assert L.lvae_gemm_f32(ctypes.byref(d), ctypes.c_void_p(stream.cuda_stream)) == 0
+
+    refs = []
+    for c in cases:
+        out = torch.empty(c['M'], c['N'], device='cuda'); ws = torch.empty(c['S'] * c['M'] * c['N'], device='cuda')
+        launch(c, out, ws, None, torch.cuda.current_stream(), False)
+        torch.cuda.synchronize()
+        refs.append(out)
+    bufs = []
+    for si, stq in enumerate(streams):      # per stream: its own workspace + counters (as the two pipeline groups have), shared by all shapes
+        ws = torch.empty(max(c['S'] * c['M'] * c['N'] for c in cases), device='cuda')
+        bufs.append((ws, torch.zeros(8192, dtype=torch.int32, device='cuda')))
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(6):
+        outs = []
+        for i in range(len(cases) * 2):
+            si = i % 2
+            ci = (i // 2 + rep * (si + 1)) % len(cases)
+            c = cases[ci]
+            out = torch.empty(c['M'], c['N'], device='cuda')
+            launch(c, out, bufs[si][0], bufs[si][1], streams[si], True)
+            outs.append((out, refs[ci]))
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(o, r) else 1 for o, r in outs)
+    assert bad == 0
+    assert all(int(b[1].abs().sum().item()) == 0 for b in bufs)
 
 
 @pytest.mark.parametrize('C,k,H,W,B', [(192, 7, 96, 160, 7), (128, 7, 61, 99, 18), (192, 5, 70, 130, 11), (128, 5, 64, 128, 12),
