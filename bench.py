@@ -6,11 +6,19 @@ resident in HBM, `compress` then `decompress`, device sync after each phase, hos
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" = one pass of the hot path over one batch: compress_batch(8 images) + decompress_batch(8 strings).
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (fp32-MFMA MLP GEMMs, 87% of the path's FLOPs): algorithmic FLOPs of those
-                  launches / their HIP-event-measured durations over the timed region, against 157.3 TFLOP/s;
-  cpu_baseline -- the CPU oracle (oracle/qarv_oracle.py: the reference's op graph on PyTorch CPU + the plain-C
-                  restatement of CompressAI's coder) timed on this node's host cores on a bounded sample.
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      -- the dominant kernel family (the PLAIN channel-mixing GEMMs: MLP fc1/fc2 + 1x1 convs, 87% of the path's FLOPs):
+                   algorithmic FLOPs of those launches / their HIP-event-measured durations (extra single-stream steps after the
+                   timed region).  Default arithmetic bf16x3: against 2500/6 = 416.7 TFLOP/s (six bf16 MFMAs per fp32-accurate
+                   product step); --precision fp32: against the 157.3 TFLOP/s fp32 MFMA peak; --precision bf16 / fp8: HBM-bound,
+                   algorithmic bytes against 8 TB/s.  `traffic` (HBM bytes per launch) cannot be read from inside this process: it
+                   is copied from the committed rocprofv3 --pmc passes of the same command and labelled so (`traffic_source`);
+  roofline_e2e  -- the whole step: algorithmic GEMM FLOPs of one step / ms_per_step against both matrix peaks;
+  fp32_mfma_mode_value -- the same workload with the exact fp32 MFMA arithmetic (a few extra steps after the timed region);
+  host_coder    -- rANS encode / decode rate of the native host coder on this step's symbols (Msymbols/s, threads);
+  cpu_baseline  -- the CPU oracle (oracle/qarv_oracle.py: the reference's op graph on PyTorch CPU + the plain-C restatement of
+                   CompressAI's coder, fed with arrays) on the node's PHYSICAL cores, `cpu_baseline_8core` = the same on 8 threads
+                   (comparable with the README's 10700K figure); bounded samples of the same workload.
 Weights are seeded random-init of the qarv_base architecture (no network for checkpoints); data is synthetic.
 """
 import argparse
@@ -87,9 +95,22 @@ class KernelTimer:
         return tot, len(self.pairs)
 
 
-def cpu_baseline(sd, H, W, n_images=12, threads=16):
-    """Bounded sample of the same workload on the host: oracle enc+dec of n_images 512x768 images (after 1 warm-up)."""
-    from oracle import qarv_oracle
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(sd, H, W, n_images, threads):
+    """Bounded sample of the same workload on the host: oracle enc+dec of n_images HxW images (after 1 warm-up image) with
+    torch.set_num_threads(threads); the plain-C coder is fed with numpy arrays (array_io), not CompressAI's Python lists."""
+    from oracle import compressai_semantics, qarv_oracle
+    compressai_semantics.EntropyModel.array_io = True
     orc = qarv_oracle.QarvOracle({k: v for k, v in sd.items()})
     orc.compress_mode()
     torch.set_num_threads(threads)
@@ -103,7 +124,38 @@ def cpu_baseline(sd, H, W, n_images=12, threads=16):
     dt = time.time() - t0
     return {'value': round(n_images * H * W / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': int(cores), 'kind': 'port',
             'sample': f'{n_images} synthetic {H}x{W} images enc+dec (after 1 warm-up image), oracle/qarv_oracle.py: PyTorch-CPU '
-                      f'fp32 op graph + plain-C CompressAI-style rANS via Python lists, {dt:.1f} s'}
+                      f'fp32 op graph + plain-C CompressAI-style rANS fed with arrays, {dt:.1f} s'}
+
+
+def host_coder_rate(model, strings, B, H, W):
+    """rANS rate of the native host coder alone, on the symbols of the benchmark's own batch (decode then re-encode of every
+    stream, all coder threads): Msymbols/s each way."""
+    import numpy as np
+    from lvae.models.entropy_coding import rans_decode_streams, rans_encode_streams
+    from lvae.utils import coding
+    tables = model._dg().host_tables()
+    pl = next(p for k, p in model._plans.items() if k[0] == 'dec' and k[1] == B and k[4] == 0 and k[-1] == model._prec)
+    shapes = pl.lat_shapes                                     # (z, hw) per latent block
+    streams, idxs, outs = [], [], []
+    # indexes are not in the container: decode needs them from the GPU; use the plan's host mirror of the LAST decode (group 0)
+    n_img = pl.B
+    for b in range(n_img):
+        per = coding.unpack_byte_string(strings[b][10:])
+        for li, (z, hw) in enumerate(shapes):
+            o = pl.idx_off[li] + b * z * hw
+            streams.append(per[li]); idxs.append(pl.idx_np[o:o + z * hw].copy()); outs.append(np.empty(z * hw, dtype=np.int32))
+    nsym = sum(i.size for i in idxs)
+    nthreads = model.coder_threads
+    t0 = time.time()
+    rans_decode_streams(tables, streams, idxs, outs, nthreads)
+    t1 = time.time()
+    enc = rans_encode_streams(tables, outs, idxs, nthreads)
+    t2 = time.time()
+    assert enc == streams
+    return {'symbols': int(nsym), 'streams': len(streams), 'threads': int(nthreads or (os.cpu_count() or 0)),
+            'decode_msym_s': round(nsym / (t1 - t0) / 1e6, 1), 'encode_msym_s': round(nsym / (t2 - t1) / 1e6, 1),
+            'note': 'native C++ coder (lvae_rans_*_batch) alone: one call decoding / re-encoding every stream of one pipeline '
+                    "group's images (9 latent blocks each); bytes re-encoded == bytes decoded"}
 
 
 def main():
@@ -117,10 +169,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3)
-    ap.add_argument('--precision', type=str, default='bf16x3', choices=['fp32', 'bf16x3', 'bf16'],
+    ap.add_argument('--precision', type=str, default='bf16x3', choices=['fp32', 'bf16x3', 'bf16', 'fp8'],
                     help="GEMM arithmetic: bf16x3 (default) = fp32-class accuracy from exact 3-term bf16 splits on the bf16 MFMA; "
-                         "fp32 = exact fp32 MFMA; bf16 = BASELINE config 5 style reduced precision (not a parity path)")
-    ap.add_argument('--cpu-threads', type=int, default=16)
+                         "fp32 = exact fp32 MFMA; bf16 = operands rounded to bf16; fp8 = BASELINE config 5: bf16 activation storage + "
+                         "MX-fp8 MFMA (bf16 / fp8 are not parity paths)")
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the main cpu_baseline row (0 = physical cores)')
+    ap.add_argument('--fp32-steps', type=int, default=3, help='extra steps in the exact fp32 MFMA mode (0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -205,74 +259,117 @@ def main():
         stats = torch.stack(gathered).mean(0)
     bpp, mse = float(stats[0]), float(stats[1])
 
+    import ctypes
+    from lvae._native import GemmDesc
+
+    def gemm_descs(plans, pred):
+        for key, pl in plans:
+            for fn, a, label in pl.ops:
+                if pred(fn, a, label):
+                    yield ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
+
+    def alg_bytes_of(d):
+        """Algorithmic HBM bytes of one GEMM launch: A and the result (+ the residual rows) once, the weights once."""
+        ea = 2 if d.a_bf16 else 4
+        eo = 2 if d.out_bf16 else 4
+        ew = {0: 4, 1: 2, 2: 6, 3: 1}[d.prec]
+        return ea * d.M * d.K + ew * d.N * d.K + eo * d.M * d.N * (2 if d.epi in (2, 3) else 1)
+
+    def any_gemm(fn, a, label):
+        return fn is _nat.lib().lvae_gemm_f32
+
+    # whole-step algorithmic GEMM FLOPs (every GEMM launch of the encode + decode plans of the timed configuration)
+    timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
+    step_gflop = sum(2.0 * d.M * d.N * d.K for d in gemm_descs(timed_plans, any_gemm)) / 1e9
+    ms_step = dt / args.steps * 1e3
+    e2e_tf = step_gflop / ms_step                          # GFLOP / ms = TFLOP/s
+    roofline_e2e = {
+        'gemm_gflop_per_step': round(step_gflop, 1), 'ms_per_step': round(ms_step, 3), 'achieved_tflops': round(e2e_tf, 2),
+        'frac_of_bf16x3_peak_416.7': round(e2e_tf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
+        'frac_of_fp32_mfma_peak_157.3': round(e2e_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+        'note': 'algorithmic 2*M*N*K of EVERY GEMM launch of one step / wall time of the step (host rANS, depthwise and pointwise '
+                'kernels included in the time, not in the FLOPs)'}
+
     roof = None
     if not args.no_kernel_timing:
         # Roofline pass: the timed region above runs the product configuration (two pipeline groups on two HIP streams,
         # whose kernels interleave on the GPU, so an event pair around one launch would also time the other stream's
         # kernels).  The dominant kernel is therefore timed in `roofline_steps` EXTRA steps of the same workload on a
-        # single stream, every fc1/fc2 launch bracketed by HIP events on that stream.
+        # single stream, every such launch bracketed by HIP events on that stream.
         model.pipeline_groups = 1
         step()                                           # builds the single-group plans (untimed)
-        for pl in model._plans.values():
+        single = [(k, pl) for k, pl in model._plans.items() if k[1] == B and k[-1] == args.precision]
+        for _, pl in single:
             pl.run = timer.wrap(pl, dominant)
         for _ in range(args.roofline_steps):
             step()
         torch.cuda.synchronize(dev)
+        for _, pl in single:
+            del pl.run                                   # back to Plan.run
         ms, n_launch = timer.summary()
-        flops = 0
-        for pl in model._plans.values():
-            pass
-        # algorithmic FLOPs of the timed launches: 2*M*N*K per MLP GEMM (bias/GELU/residual epilogues not counted)
-        import ctypes
-        from lvae._native import GemmDesc
-        per_step = 0
-        alg_bytes = 0
-        for key, pl in model._plans.items():
-            if key[1] != B:                              # only the single-group (full batch) plans were timed
-                continue
-            for fn, a, label in pl.ops:
-                if dominant(fn, a, label):
-                    d = ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
-                    per_step += 2 * d.M * d.N * d.K
-                    alg_bytes += 4 * (d.M * d.K + d.N * d.K + d.M * d.N * (2 if d.epi in (2, 3) else 1))
+        per_step = sum(2 * d.M * d.N * d.K for d in gemm_descs(single, dominant))
+        alg_bytes = sum(alg_bytes_of(d) for d in gemm_descs(single, dominant))
         flops = per_step * args.roofline_steps
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof_hbm = {'bound': 'hbm', 'kernel': 'gemm_bf16_kernel<Cfg<*>, 0> (all PLAIN bf16-MFMA GEMM launches; bound by the fp32 operand/result streams)',
-                    'achieved': round(alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0, 'peak': 8000.0,
-                    'unit': 'GB/s', 'frac': round(alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms > 0 else 0.0,
-                    'traffic': None, 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
-                    'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
-                    'tflops_equiv': round(ach, 2)}
-        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<Cfg<*>, 0> (all PLAIN fp32-MFMA GEMM launches: MLP fc1/fc2 + 1x1 convs; v_mfma_f32_32x32x2_f32)',
-                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
-                'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
-                'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
-                'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
-                'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every such launch',
-                'traffic_note': 'HBM bytes are collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE): profiles/'}
-
-    if roof is not None and args.precision == 'bf16':
-        roof = roof_hbm
-    if roof is not None and args.precision == 'bf16x3':
-        # algorithmic fp32 FLOPs against the bf16 dense MFMA peak divided by the 6 MFMAs each product step costs
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        roof.update({'kernel': 'gemm_x3k16_kernel<TN> / gemm_x3w8_kernel / gemm_x3_kernel<Cfg<*>, 0> (all PLAIN GEMM launches; '
-                               'v_mfma_f32_32x32x16_bf16 x 6 cross terms)',
-                     'peak': round(peak, 1), 'frac': round(roof['achieved'] / peak, 4),
-                     'peak_note': '2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product step; vs the 157.3 TFLOP/s fp32 MFMA '
-                                  f"peak this launch family runs at {roof['achieved'] / PEAK_FP32_MFMA_TFLOPS:.3f}"})
-    if roof is not None and args.precision == 'bf16x3' and (B, H, W) == (8, 512, 768):
-        # PMC-measured HBM bytes per launch of the same launch family, from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # passes of this workload (tools/prof_round.sh -> tools/pmc_traffic.py); counters cannot be read from inside this process
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_traffic_v8.json')
-        if os.path.exists(tp):
+        gbs = alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        common = {'traffic': None, 'traffic_source': None, 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
+                  'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
+                  'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
+                  'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every such launch'}
+        if args.precision in ('bf16', 'fp8'):
+            kern = {'bf16': 'gemm_bf16_kernel<Cfg<*>, 0> (PLAIN GEMM launches: operands rounded to bf16 on the bf16 MFMA, fp32 maps in HBM)',
+                    'fp8': 'gemm_lp_kernel<TN, 0, *, *> (PLAIN GEMM launches of the reduced-precision mode: bf16 maps in HBM, operands '
+                           'quantised to MX-fp8 for v_mfma_scale_f32_32x32x64_f8f6f4)'}[args.precision]
+            roof = {'bound': 'hbm', 'kernel': kern, 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                    'tflops_equiv': round(ach, 2), **common}
+        elif args.precision == 'fp32':
+            roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<Cfg<*>, 0> (PLAIN GEMM launches: MLP fc1/fc2 + 1x1 convs; v_mfma_f32_32x32x2_f32)',
+                    'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **common}
+        else:
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0           # algorithmic fp32 FLOPs vs the dense bf16 MFMA peak / 6 MFMAs per product step
+            roof = {'bound': 'mfma', 'kernel': 'gemm_x3k16_kernel<TN> / gemm_x3w8_kernel / gemm_x3_kernel<Cfg<*>, 0> (PLAIN GEMM launches; '
+                                               'v_mfma_f32_32x32x16_bf16 x 6 cross terms)',
+                    'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'peak_note': '2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product step; vs the 157.3 TFLOP/s fp32 MFMA '
+                                 f'peak this launch family runs at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}', **common}
+        # HBM bytes per launch of this family: NOT measured in this run (hardware counters cannot be read from inside the process);
+        # copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command
+        tfile = {('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r02_pmc_gemm_traffic_fp8_1216.json',
+                 ('fp8', 8, 512, 768): 'r02_pmc_gemm_traffic_fp8.json'}.get((args.precision, B, H, W))
+        tp = os.path.join(REPO, 'profiles', tfile) if tfile else None
+        if tp and not os.path.exists(tp) and args.precision == 'bf16x3':
+            tp = os.path.join(REPO, 'profiles', 'r01_pmc_gemm_traffic_v8.json')
+        if tp and os.path.exists(tp):
             tj = json.load(open(tp))
             roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 1e6)
-            roof['traffic_note'] = ('bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over '
-                                    f"{tj['launches']} launches of this family (profiles/r01_pmc_gemm_traffic_v8.json, "
-                                    'profiles/r01_pmc_hbm_traffic_v8.txt); below the algorithmic bytes because producer outputs are '
-                                    'still resident in the 256 MiB Infinity Cache when the GEMM reads them')
+            roof['traffic_source'] = (f'NOT measured in this run: bytes per launch from the committed rocprofv3 --pmc passes of this '
+                                      f"command (profiles/{os.path.basename(tp)}: FETCH_SIZE x2 + WRITE_SIZE over {tj['launches']} launches "
+                                      'of this kernel family); producer outputs still resident in the 256 MiB Infinity Cache are not '
+                                      'counted by the memory-side counters')
+
+    fp32_mode = None
+    if world == 1 and args.fp32_steps > 0 and args.precision == 'bf16x3':
+        # the same workload with the exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), product configuration (two groups)
+        model.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+        model.set_gemm_precision('fp32')
+        step()
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        for _ in range(args.fp32_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        fp32_mode = round(B * H * W * args.fp32_steps / (time.time() - t1) / 1e6, 3)
+        model.set_gemm_precision(args.precision)
+
+    coder = None
+    if rank == 0:
+        try:
+            model.pipeline_groups = 1
+            strings1, _, _ = step()
+            coder = host_coder_rate(model, strings1, B, H, W)
+        except Exception as e:                           # diagnostic only: never lose the bench line over it
+            coder = {'error': repr(e)}
+
     if rank == 0 and model.timing is not None:
         print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)
     if rank == 0:
@@ -283,19 +380,23 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16x3': 'f32 (exact 3-term bf16 split of every fp32 operand, 6 bf16 MFMAs per product step, '
                                                'fp32 accumulate: fp32-class accuracy, parity-tested)',
-                      'bf16': 'bf16-mfma (f32 activations/accumulate; NOT the parity path)'}[args.precision], 'data': 'synthetic',
+                      'bf16': 'bf16-mfma (f32 activations/accumulate; NOT the parity path)',
+                      'fp8': 'mxfp8-mfma (OCP e4m3 + E8M0 block scales, f32 accumulate) with bf16 activation storage: BASELINE config 5, '
+                             'NOT the parity path'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
-                                   f'fp32 HIP kernels + host rANS, seeded random-init weights (profile {PROFILE})', 'global_batch': world * B,
+                                   f'HIP kernels ({args.precision}) + host rANS, seeded random-init weights (profile {PROFILE})', 'global_batch': world * B,
                        'parallelism': f'dp{world} (images sharded, no data-path collective)',
                        'lambda': model.default_lmb},
             'enc_ms_per_step': round(t_enc / args.steps * 1e3, 3),
             'dec_ms_per_step': round((dt - t_enc) / args.steps * 1e3, 3),
             'bpp': round(bpp, 4), 'psnr_db': round(-10 * np.log10(mse), 3),
             'ref_3080ti_mpx_s': 2.47,
-            'roofline': roof,
+            'roofline': roof, 'roofline_e2e': roofline_e2e, 'fp32_mfma_mode_value': fp32_mode, 'host_coder': coder,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, H, W, threads=args.cpu_threads)
+            phys = args.cpu_threads or physical_cores()
+            line['cpu_baseline'] = cpu_baseline(sd, H, W, n_images=max(4, min(16, phys // 8)), threads=phys)
+            line['cpu_baseline_8core'] = cpu_baseline(sd, H, W, n_images=3, threads=8)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

@@ -118,6 +118,10 @@ typedef struct {
                                              2: "bf16x3": each fp32 operand split exactly into hi+mid+lo bf16 terms, six
                                                 cross-term bf16 MFMAs per step, fp32 accumulate -- fp32-class accuracy
                                                 (relative error of a product <= 2^-24).  prec 1/2 need Wt16, K % 8 == 0 */
+                                          /* 3: REDUCED precision (BASELINE config 5): activations stored as bf16, operands quantised to
+                                                OCP MX-fp8 (e4m3 + one E8M0 scale per 32 k) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32
+                                                accumulate; Wt16 = [N][ldw] e4m3 bytes then [N][ldw/32] scale bytes, ldw = K rounded
+                                                up to 64 (zero padded; lvae.models.base.pack_mxfp8).  Not a parity path */
     const unsigned short* Wt16;           /* prec 1: weights as bf16 bit patterns, [N][K], row stride ldw;
                                              prec 2: three such planes hi | mid | lo, plane stride N*ldw elements,
                                              followed -- when K % 32 == 0 and ldw == K -- by the same values in
@@ -131,6 +135,8 @@ typedef struct {
                                              heads).  Row-major store only, N % 4 == 0.  The host must choose S independently of
                                              the batch size (per-image rows), so that batched and single-image calls agree */
     float* ws;                            /* split-K workspace, S*M*N floats (unused when ksplit <= 1) */
+    int  a_bf16, out_bf16;                /* prec 3 only: A (both sources) / out and res are bf16 bit patterns (2-byte elements;
+                                             lda, ldo, ldres stay in ELEMENTS); 0 = fp32.  The final NCHW image is always fp32 */
     int* cnt;                             /* split-K arrival counters, one int per output tile (>= ceil(M/64)*ceil(N/32) entries covers
                                              every tile shape), ZERO before the first launch; each launch leaves them zero again.
                                              Non-NULL: the last slice workgroup of a tile to arrive reduces the S slabs in slice order
@@ -147,6 +153,15 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                        const float* shift, const float* scale1p, float* y,
                        int B, int H, int W, int C, int k, void* stream);
+
+/* bf16-storage forms of the reduced-precision mode (BASELINE config 5; prec 3 of lvae_gemm_f32): x / y / out are bf16 bit patterns
+ * (NHWC, 2-byte elements), arithmetic in fp32 registers, parameters fp32.  Same semantics as the _f32 entry points otherwise. */
+int lvae_dwconv_ln_bf16(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                        const float* shift, const float* scale1p, void* y,
+                        int B, int H, int W, int C, int k, void* stream);
+int lvae_stem_bf16(const float* im, const float* wt, const float* bias, void* out,
+                   int B, int H, int W, int Cout, float im_shift, float im_scale, int* range_flag, void* stream);
+int lvae_bias_expand_bf16(const float* bias, void* out, long M, int C, void* stream);
 
 /* Stem: NCHW image [B][3][H][W] in [0,1] -> (im+shift)*scale (qarv/model.py:221) -> conv 4x4/stride 4
  * (zoo.py:37) -> NHWC [B][H/4][W/4][Cout].  wt is [48][Cout] with k = (ci*4+i)*4+j. Cout <= 256, multiple of 64. */

@@ -659,6 +659,7 @@ __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
+int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn);
 static int gemm_dispatch(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) { return gemm_dispatch_impl(d, st, x3v2, x3v2_tn); }
 
@@ -673,7 +674,14 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     }
     if (!d || !d->A0 || (!d->Wt && !(d->prec != 0 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
-    if (d->prec < 0 || d->prec > 2) return -22;
+    if (d->prec < 0 || d->prec > 3) return -22;
+    if (d->prec != 3 && (d->a_bf16 || d->out_bf16)) return -22;      // bf16 storage exists in the reduced-precision mode only
+    if (d->prec == 3) {
+        if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
+        if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
+        if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;
+        return lvae_gemm_lp_dispatch(d, (hipStream_t)stream);
+    }
     if (d->prec != 0 && (!d->Wt16 || (d->K & 7) || (d->ldw & 7))) return -22;
     if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
     if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;

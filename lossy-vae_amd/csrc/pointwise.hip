@@ -20,6 +20,32 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Activation storage of the reduced-precision mode (BASELINE config 5): bf16 bit patterns, fp32 arithmetic in registers.
+// BF = false: plain fp32 maps (the parity path).  Offsets are in ELEMENTS.
+template <bool BF>
+__device__ __forceinline__ f32x4 ld4(const void* base, long off) {
+    if (BF) {
+        const u32x2 q = *(const u32x2*)((const unsigned short*)base + off);
+        return (f32x4){__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16),
+                       __uint_as_float(q[1] & 0xffff0000u)};
+    }
+    return *(const f32x4*)((const float*)base + off);
+}
+__device__ __forceinline__ unsigned f2bf(float x) {            // round to nearest even
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <bool BF>
+__device__ __forceinline__ void st4(void* base, long off, f32x4 v) {
+    if (BF) {
+        const u32x2 q = {f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16)};
+        *(u32x2*)((unsigned short*)base + off) = q;
+    } else {
+        *(f32x4*)((float*)base + off) = v;
+    }
+}
 
 
 // ------------------------------------------------------------------------------------------------ dwconv + LN + AdaLN
@@ -28,11 +54,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // along W in registers: (TW+k-1) input float4 per kernel row feed TW outputs, i.e. ~(TW+k-1)/TW loads per output tap
 // row instead of k.  LayerNorm statistics are reduced across the LPP lanes with xor-shuffles (two-pass variance on the
 // register-resident conv outputs).
-template <int KS, int VPL, int LPP, int TH>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+template <int KS, int VPL, int LPP, int TH, bool BF = false>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const void* __restrict__ x, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, const float* __restrict__ shift,
-                                                        const float* __restrict__ scale1p, float* __restrict__ y,
+                                                        const float* __restrict__ scale1p, void* __restrict__ y,
                                                         int B, int H, int W, int gpr, int hgr, long total_groups) {
     constexpr int TW = 4;
     constexpr int C = 4 * VPL * LPP;
@@ -75,13 +101,13 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
         for (int r = 0; r < KS + TH - 1; ++r) {
             const int hh = h0 + r - P;
             const bool rv = (hh >= 0) && (hh < H);
-            const float* xrow = x + ((brow + hh) * W) * (long)C + c;
+            const long xrow = ((brow + hh) * W) * (long)C + c;
             f32x4 xr[TW + KS - 1];
 #pragma unroll
             for (int q = 0; q < TW + KS - 1; ++q) {
                 const int ww = w0 + q - P;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                xr[q] = (rv && ww >= 0 && ww < W) ? *(const f32x4*)(xrow + (long)ww * C) : z;
+                xr[q] = (rv && ww >= 0 && ww < W) ? ld4<BF>(x, xrow + (long)ww * C) : z;
             }
 #pragma unroll
             for (int th = 0; th < TH; ++th) {
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
             const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
             const int ww = w0 + t, hh = h0 + th;
             if (active && ww < W && hh < H) {
-                float* yp = y + (((brow + hh) * W) + ww) * (long)C;
+                const long yp = (((brow + hh) * W) + ww) * (long)C;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
                     const int c = 4 * (cl + v * LPP);
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
                     }
-                    *(f32x4*)(yp + c) = o4;
+                    st4<BF>(y, yp + c, o4);
                 }
             }
         }
@@ -322,15 +348,15 @@ int launch_dwln_tile(const float* x, const float* wt, const float* bias, const f
 
 int g_dw_th = 0;       // tuning hook (LVAE_DW_TH): 1 or 2 output rows per group; 0 = heuristic
 
-template <int KS, int VPL, int LPP, int TH>
-int launch_dwln_th(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
-                   const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
+template <int KS, int VPL, int LPP, int TH, bool BF = false>
+int launch_dwln_th(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                   const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
     const int gpr = (W + 3) / 4, hgr = (H + TH - 1) / TH;
     const long total = (long)B * hgr * gpr;
     const int gpw = 64 / LPP;
     const long waves = (total + gpw - 1) / gpw;
     const long blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL((dwconv_ln_kernel<KS, VPL, LPP, TH>), dim3((unsigned)blocks), dim3(256), 0, st, x, wt, bias, ln_w, ln_b,
+    hipLaunchKernelGGL((dwconv_ln_kernel<KS, VPL, LPP, TH, BF>), dim3((unsigned)blocks), dim3(256), 0, st, x, wt, bias, ln_w, ln_b,
                        shift, scale1p, y, B, H, W, gpr, hgr, total);
     return (int)hipGetLastError();
 }
@@ -367,14 +393,29 @@ int dispatch_dwln_c(int C, const float* x, const float* wt, const float* bias, c
     return -22;
 }
 
+// bf16-storage form (reduced-precision mode): the register sliding-window kernel, one output row per group
+template <int KS>
+int dispatch_dwln_bf16(int C, const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                       const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
+    switch (C) {
+        case 128: return launch_dwln_th<KS, 2, 16, 1, true>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 192: return launch_dwln_th<KS, 3, 16, 1, true>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 256: return launch_dwln_th<KS, 2, 32, 1, true>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 384: return launch_dwln_th<KS, 3, 32, 1, true>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 512: return launch_dwln_th<KS, 4, 32, 1, true>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    }
+    return -22;
+}
+
 // ------------------------------------------------------------------------------------------------ stem
 // One block = 64 output pixels x Cout channels (thread n = output channel, its 48 weights live in registers; the
 // 64x48 preprocessed patch matrix is staged in LDS and read as wave-uniform broadcasts).
 // range_flag (optional): the reference's input contract `0 <= im.min() <= im.max() <= 1` (qarv/model.py:219-220, qresvae/model.py:492)
 // checked on the values this kernel loads anyway: bit 0 of *range_flag is set when any pixel is outside [0, 1] or NaN; the host
 // reads the flag at a synchronisation point it already has (no extra device sync, unlike the reference's .min()/.max()).
+template <bool BF>
 __global__ void stem_kernel(const float* __restrict__ im, const float* __restrict__ wt, const float* __restrict__ bias,
-                            float* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M,
+                            void* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M,
                             int* __restrict__ range_flag) {
     __shared__ __attribute__((aligned(16))) float patch[64][48];
     const int n = threadIdx.x;
@@ -415,7 +456,8 @@ __global__ void stem_kernel(const float* __restrict__ im, const float* __restric
             a = fmaf(pv[2], wr[k4 * 4 + 2], a);
             a = fmaf(pv[3], wr[k4 * 4 + 3], a);
         }
-        out[pg * Cout + n] = a;
+        if (BF) ((unsigned short*)out)[pg * Cout + n] = (unsigned short)f2bf(a);
+        else ((float*)out)[pg * Cout + n] = a;
     }
 }
 
@@ -666,8 +708,48 @@ extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias
                              int Cout, float im_shift, float im_scale, int* range_flag, void* stream) {
     if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256) return -22;
     const long M = (long)B * (H / 4) * (W / 4);
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
+    hipLaunchKernelGGL(stem_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
                        B, H, W, Cout, im_shift, im_scale, M, range_flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_stem_bf16(const float* im, const float* wt, const float* bias, void* out, int B, int H, int W,
+                              int Cout, float im_shift, float im_scale, int* range_flag, void* stream) {
+    if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256) return -22;
+    const long M = (long)B * (H / 4) * (W / 4);
+    hipLaunchKernelGGL(stem_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(Cout), 0, (hipStream_t)stream, im, wt, bias, out,
+                       B, H, W, Cout, im_shift, im_scale, M, range_flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_dwconv_ln_bf16(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                                   const float* shift, const float* scale1p, void* y, int B, int H, int W, int C, int k,
+                                   void* stream) {
+    if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
+    if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return dispatch_dwln_bf16<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 3: return dispatch_dwln_bf16<3>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 5: return dispatch_dwln_bf16<5>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+        case 7: return dispatch_dwln_bf16<7>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
+    }
+    return -22;
+}
+
+namespace {
+__global__ void bias_expand_bf16_kernel(const float* __restrict__ bias, unsigned short* __restrict__ out, long total4, int C4) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    st4<true>(out, e * 4, ((const f32x4*)bias)[e % C4]);
+}
+}  // namespace
+
+extern "C" int lvae_bias_expand_bf16(const float* bias, void* out, long M, int C, void* stream) {
+    if (!bias || !out || M <= 0 || C <= 0 || (C & 3)) return -22;
+    const long total4 = M * (C / 4);
+    hipLaunchKernelGGL(bias_expand_bf16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bias,
+                       (unsigned short*)out, total4, C / 4);
     return (int)hipGetLastError();
 }
 
@@ -792,5 +874,5 @@ extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 10; }
+extern "C" int lvae_abi_version(void) { return 11; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

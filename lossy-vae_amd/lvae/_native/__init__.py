@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 
@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ('out', C.c_void_p), ('ldo', C.c_long),
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
-        ('a_gelu', C.c_int), ('prec', C.c_int), ('Wt16', C.c_void_p), ('cfg', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('cnt', C.c_void_p),
+        ('a_gelu', C.c_int), ('prec', C.c_int), ('Wt16', C.c_void_p), ('cfg', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('a_bf16', C.c_int), ('out_bf16', C.c_int), ('cnt', C.c_void_p),
     ]
 
 
@@ -50,6 +50,9 @@ SIGNATURES = {
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'lvae_range_flag_f32': (_i, [_vp, _l, _f, _f, _vp, _vp]),
+    'lvae_dwconv_ln_bf16': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
+    'lvae_stem_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    'lvae_bias_expand_bf16': (_i, [_vp, _vp, _l, _i, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -98,7 +98,8 @@ class Plan:
         self.keep = []         # tensors / descs that must outlive the plan
         self.bufs = {}
         self.flops = 0
-        self.prec = 0          # lvae_gemm_desc.prec for this plan's GEMMs (0 fp32, 1 bf16, 2 bf16x3)
+        self.prec = 0          # lvae_gemm_desc.prec for this plan's GEMMs (0 fp32, 1 bf16, 2 bf16x3, 3 MX-fp8 + bf16 storage)
+        self.adt = torch.float32   # storage type of the feature maps (bfloat16 in the reduced-precision mode)
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
@@ -144,7 +145,7 @@ class Plan:
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, a_bf16=None, out_bf16=None, label='gemm'):
         if K is None:
             K = K0 + K1
         if Wt16 is None and self.w16 is not None:
@@ -164,6 +165,13 @@ class Plan:
         # 0/1 weights: nearest upsampling, space-to-depth -- x*1 + 0*... must reproduce x bit for bit)
         d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
         d.Wt16 = Wt16 if d.prec else None
+        if self.prec == 3:
+            # reduced-precision plans (BASELINE config 5): bf16 maps in HBM, MX-fp8 operands; weight rows are padded to 64 k
+            assert d.prec == 3, f'{label}: no MX-fp8 form of this GEMM (K={K})'
+            d.ldw = (K + 63) // 64 * 64
+            d.a_bf16 = 1 if a_bf16 is None else int(a_bf16)
+            d.out_bf16 = (0 if store == _native.ST_IMAGE else 1) if out_bf16 is None else int(out_bf16)
+            ksplit = 1
         if ksplit is None:
             ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
         if ksplit > 1:

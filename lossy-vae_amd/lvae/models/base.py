@@ -33,6 +33,36 @@ def pack_bf16x3(t):
     return torch.cat([planes.reshape(-1), inter.reshape(-1)])
 
 
+def pack_mxfp8(t):
+    """The prec-3 weight buffer of lvae_gemm_f32 for an [N][K] fp32 weight: OCP MX-fp8 -- e4m3 elements with one E8M0
+    (power-of-two) scale per 32 consecutive k of a row -- as a uint8 tensor: [N][Kp] element bytes followed by [N][Kp/32] scale
+    bytes, Kp = K rounded up to a multiple of 64 (zero padded).  Block scale: 2^e with amax / 2^e in (224, 448] (e4m3's largest
+    finite value is 448); elements rounded to nearest even by torch's float8_e4m3fn conversion -- the same rule the kernel applies
+    to activations with v_cvt_pk_fp8_f32."""
+    n, k = t.shape
+    kp = (k + 63) // 64 * 64
+    w = torch.zeros(n, kp, dtype=torch.float32, device=t.device)
+    w[:, :k] = t.float()
+    blk = w.view(n, kp // 32, 32)
+    amax = blk.abs().amax(dim=2)
+    bits = amax.view(torch.int32)
+    eb = ((bits >> 23) & 0xff) - 8
+    eb = eb + ((bits & 0x7fffff) > 0x600000).to(torch.int32)
+    eb = eb.clamp(0, 254)
+    inv = ((254 - eb) << 23).view(torch.float32)                      # 2^(127 - eb), exact
+    q = (blk * inv.unsqueeze(2)).to(torch.float8_e4m3fn).view(torch.uint8).reshape(n, kp)
+    return torch.cat([q.reshape(-1), eb.to(torch.uint8).reshape(-1)]).contiguous()
+
+
+def unpack_mxfp8(buf, n, k):
+    """Inverse of pack_mxfp8 (tests): the fp32 values the MX-fp8 weights stand for, [N][K]."""
+    kp = (k + 63) // 64 * 64
+    q = buf[:n * kp].view(torch.float8_e4m3fn).float().view(n, kp // 32, 32)
+    eb = buf[n * kp:].to(torch.int32).view(n, kp // 32)
+    scale = torch.pow(2.0, (eb - 127).double()).float()
+    return (q * scale.unsqueeze(2)).view(n, kp)[:, :k].contiguous()
+
+
 class LazyW16:
     """{address of an fp32 GEMM weight: address of its reduced-precision copy}, filled ON FIRST USE by Plan.gemm: only tensors
     that are actually passed as `Wt` get a bf16 / bf16x3 copy (the packed dict also holds the AdaLN matrix, depthwise tables,
@@ -53,7 +83,8 @@ class LazyW16:
         with _W16_LOCK:
             h = self.map.get(ptr)
             if h is None:
-                c = pack_bf16x3(t) if self.mode == 'bf16x3' else t.to(torch.bfloat16).contiguous()
+                c = (pack_bf16x3(t) if self.mode == 'bf16x3' else pack_mxfp8(t) if self.mode == 'mxfp8'
+                     else t.to(torch.bfloat16).contiguous())
                 self.keep.append(c)
                 h = self.map[ptr] = c.data_ptr()
         return h
@@ -69,11 +100,17 @@ def bf16_weight_map(tensors):
     return m, m.keep
 
 
+def mxfp8_weight_map(tensors):
+    m = LazyW16(tensors, 'mxfp8')
+    return m, m.keep
+
+
 # GEMM arithmetic of newly built models, read ONCE at import (LVAE_PRECISION=fp32|bf16|bf16x3).  A bitstream decodes only under the
 # arithmetic that produced it (the priors must match bit for bit) and the container -- the reference's, byte for byte -- does not
 # record it: the default is fixed (bf16x3), an explicit mode must be set identically on both sides (docs: DESIGN.md 4).
 DEFAULT_PRECISION = os.environ.get('LVAE_PRECISION', 'bf16x3')
-assert DEFAULT_PRECISION in ('fp32', 'bf16', 'bf16x3'), DEFAULT_PRECISION
+PRECISIONS = ('fp32', 'bf16', 'bf16x3', 'fp8')
+assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 
 def on_model_device(fn):
@@ -102,9 +139,10 @@ class CodecBase(nn.Module):
 
     def set_gemm_precision(self, mode):
         """'fp32': exact fp32 MFMA (fmaf chains); 'bf16x3': fp32-class accuracy from three-term bf16 splits on the bf16 MFMA
-        (2.7x less matrix-pipe time); 'bf16': operands rounded to bf16 (BASELINE config 5; visibly different numerics).
-        Bitstreams are only decodable in the mode that produced them (the priors must match bit for bit)."""
-        assert mode in ('fp32', 'bf16', 'bf16x3')
+        (2.7x less matrix-pipe time); 'bf16': operands rounded to bf16, fp32 activations in HBM; 'fp8': BASELINE config 5 --
+        activations STORED as bf16 and every channel-mixing GEMM on the block-scaled MX-fp8 MFMA (visibly different numerics,
+        half the HBM traffic).  Bitstreams are only decodable in the mode that produced them (the priors must match bit for bit)."""
+        assert mode in PRECISIONS
         self._prec = mode
 
     def _coder_threads_per_group(self, n_groups):

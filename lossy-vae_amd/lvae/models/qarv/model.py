@@ -189,12 +189,12 @@ class _Packed:
     def bf16_map(self, mode):
         """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
         builder would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, bf16x3_weight_map, _W16_LOCK
+        from ..base import bf16_weight_map, bf16x3_weight_map, mxfp8_weight_map, _W16_LOCK
         with _W16_LOCK:
             if not hasattr(self, '_w16'):
                 self._w16 = {}
             if mode not in self._w16:
-                self._w16[mode] = (bf16_weight_map if mode == 'bf16' else bf16x3_weight_map)(self.t)
+                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'fp8': mxfp8_weight_map}[mode](self.t)
         return self._w16[mode][0]
 
 
@@ -204,8 +204,11 @@ class _NetPlan(Plan):
     def __init__(self, model, pk, B):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
-        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[model._prec]
+        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'fp8': 3}[model._prec]
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
+        self.lp = self.prec == 3                # reduced precision (BASELINE config 5): feature maps stored as bf16, MX-fp8 GEMMs
+        self.adt = torch.bfloat16 if self.lp else torch.float32
+        self.dwln = self.lib.lvae_dwconv_ln_bf16 if self.lp else self.lib.lvae_dwconv_ln_f32
         self.sym_off, self.idx_off = [], []     # per latent block element offsets into sym_all / idx_all
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
         self.qcuts = []                         # encode plans: op index right after each block's quantize launch
@@ -213,8 +216,8 @@ class _NetPlan(Plan):
         self.lat_shapes = []                    # (z, HW)
 
     def scratch(self, M, C, hid):
-        y = self.buf('y', M * C)
-        h = self.buf('hid', M * hid)
+        y = self.buf('y', M * C, self.adt)
+        h = self.buf('hid', M * hid, self.adt)
         return y, h
 
     def cnx(self, p, m, x, out, H, W):
@@ -224,7 +227,7 @@ class _NetPlan(Plan):
         M = self.B * H * W
         y, h = self.scratch(M, C, hid)
         off = pk.adaln_off[p]
-        self.add(lib.lvae_dwconv_ln_f32, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
+        self.add(self.dwln, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
                                           ptr(pk.adaln, off + C), y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
         self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=h.data_ptr(),
                   epi=_native.EPI_BIAS_GELU, label=p + '.fc1')
@@ -245,7 +248,7 @@ class _NetPlan(Plan):
         self.cnx(p + '.resnet_front', m.resnet_front, f, f, H, W)
         prm = self.buf('prm', M * 2 * z)
         self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
-                  out=prm.data_ptr(), label=p + '.prior')
+                  out=prm.data_ptr(), out_bf16=0, label=p + '.prior')
         pm = self.new(M * z)
         self.pm_bufs.append(pm)
         self.prm_ptrs.append(prm.data_ptr())
@@ -261,7 +264,7 @@ class _NetPlan(Plan):
         pk = self.pk
         M = self.B * H * W
         self.gemm(A0=zhat, K0=m.zdim, M=M, N=m.width, Wt=pk.p(p + '.z_proj.w'), bias=pk.p(p + '.z_proj.b'), res=f,
-                  ldres=m.width, out=f, epi=_native.EPI_RES, label=p + '.z_proj')
+                  ldres=m.width, out=f, epi=_native.EPI_RES, a_bf16=0, label=p + '.z_proj')
         self.cnx(p + '.resnet_end', m.resnet_end, f, f, H, W)
 
     def alloc_latent_io(self, nH, nW):
@@ -300,20 +303,20 @@ class _EncPlan(_NetPlan):
             p = f'encoder.enc_blocks.{i}'
             if m.kind == 'down' and m.rate == 4:
                 h, w = h // 4, w // 4
-                x = self.new(B * h * w * m.out_channels)
-                self.add(lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
+                x = self.new(B * h * w * m.out_channels, self.adt)
+                self.add(lib.lvae_stem_bf16 if self.lp else lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
                                              m.out_channels, model.im_shift, model.im_scale, self.alloc_range_flag()), p + '.stem')
                 self.flops += 2 * B * h * w * m.out_channels * 48
             elif m.kind == 'down':
                 h, w = h // 2, w // 2
-                nx = self.new(B * h * w * m.out_channels)
+                nx = self.new(B * h * w * m.out_channels, self.adt)
                 self.gemm(A0=x.data_ptr(), K0=m.in_channels, M=B * h * w, N=m.out_channels, K=4 * m.in_channels,
                           Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'), out=nx.data_ptr(), a_mode=_native.A_PATCH2, H=h, W=w,
                           label=p + '.down')
                 x = nx
             elif m.kind == 'cnx':
                 if x.data_ptr() in tapped:               # feature was tapped by SetKey: keep it, write elsewhere
-                    nx = self.new(x.numel())
+                    nx = self.new(x.numel(), self.adt)
                     self.cnx(p, m, x.data_ptr(), nx.data_ptr(), h, w)
                     x = nx
                 else:
@@ -324,8 +327,8 @@ class _EncPlan(_NetPlan):
         # top-down path
         h, w = H // 64, W // 64
         width = model.dec_blocks[0].width
-        f = self.new(B * h * w * width)
-        self.add(lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
+        f = self.new(B * h * w * width, self.adt)
+        self.add(lib.lvae_bias_expand_bf16 if self.lp else lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
         for i, m in enumerate(model.dec_blocks):
             p = f'dec_blocks.{i}'
             if m.kind == 'vrlv':
@@ -333,9 +336,9 @@ class _EncPlan(_NetPlan):
                 pm, ioff = self.prior(p, m, f.data_ptr(), h, w)
                 ef, eh, ew = feats[m.enc_key]
                 assert (eh, ew) == (h, w)
-                e = self.buf('post_e', M * m.enc_width)
-                g = self.buf('post_g', M * m.width)
-                mg = self.buf('post_m', M * m.width)
+                e = self.buf('post_e', M * m.enc_width, self.adt)
+                g = self.buf('post_g', M * m.width, self.adt)
+                mg = self.buf('post_m', M * m.width, self.adt)
                 self.cnx(p + '.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), h, w)
                 self.cnx(p + '.posterior1', m.posterior1, f.data_ptr(), g.data_ptr(), h, w)
                 self.gemm(A0=g.data_ptr(), K0=m.width, A1=e.data_ptr(), K1=m.enc_width, lda1=m.enc_width, M=M, N=m.width,
@@ -344,7 +347,7 @@ class _EncPlan(_NetPlan):
                 self.cnx(p + '.posterior2', m.posterior2, mg.data_ptr(), mg.data_ptr(), h, w)
                 qm = self.buf('qm', M * z)
                 self.gemm(A0=mg.data_ptr(), K0=m.width, M=M, N=z, K=9 * m.width, Wt=pk.p(p + '.posterior.w'),
-                          bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w,
+                          bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w, out_bf16=0,
                           label=p + '.posterior')
                 zhat = self.buf('zhat', M * z)
                 self.sym_off.append(ioff)
@@ -359,7 +362,7 @@ class _EncPlan(_NetPlan):
             elif m.kind == 'cnx':
                 self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
             elif m.kind == 'up':
-                nf = self.new(B * h * w * m.rate ** 2 * m.cout)
+                nf = self.new(B * h * w * m.rate ** 2 * m.cout, self.adt)
                 self.upsample(p, m, f.data_ptr(), nf.data_ptr(), h, w)
                 f = nf
                 h, w = h * m.rate, w * m.rate
@@ -376,8 +379,8 @@ class _DecPlan(_NetPlan):
         self.alloc_latent_io_full(nH, nW)
         h, w = nH, nW
         width = model.dec_blocks[0].width
-        f = self.new(B * h * w * width)
-        self.add(lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
+        f = self.new(B * h * w * width, self.adt)
+        self.add(lib.lvae_bias_expand_bf16 if self.lp else lib.lvae_bias_expand_f32, (pk.p('bias'), f.data_ptr(), B * h * w, width), 'bias')
         self.cuts = []        # op index after each prior_index (host decode happens there)
         self.lat_hw = []      # (h, w) of each latent block
         self.out = None
@@ -399,7 +402,7 @@ class _DecPlan(_NetPlan):
                 self.cnx(p, m, f.data_ptr(), f.data_ptr(), h, w)
             elif m.kind == 'up':
                 final = m.cout <= 3
-                nf = self.new(B * h * w * m.rate ** 2 * m.cout)
+                nf = self.new(B * h * w * m.rate ** 2 * m.cout, torch.float32 if final else self.adt)
                 self.upsample(p, m, f.data_ptr(), nf.data_ptr(), h, w)
                 f = nf
                 h, w = h * m.rate, w * m.rate

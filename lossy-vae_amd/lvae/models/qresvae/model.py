@@ -254,6 +254,8 @@ class _QresPlan(Plan):
     def __init__(self, model, pk, B, H, W, encode):
         super().__init__(pk.device)
         lib, self.pk, self.B = self.lib, pk, B
+        if model._prec == 'fp8':
+            raise NotImplementedError("the 'fp8' mode (bf16 activation storage + MX-fp8 GEMMs, BASELINE config 5) is built for qarv_base")
         self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[model._prec]
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.lat_shapes, self.idx_off, self.sym_off, self.cuts = [], [], [], []

@@ -95,7 +95,7 @@ class RansEncoder:
 
 class RansDecoder:
     """compressai.ans.RansDecoder."""
-    def decode_with_indexes(self, encoded, indexes, cdfs, cdfs_sizes, offsets):
+    def decode_with_indexes(self, encoded, indexes, cdfs, cdfs_sizes, offsets, as_array=False):
         idx, cdf = _i32(indexes), _cdf_matrix(cdfs)
         sizes, offs = _i32(cdfs_sizes), _i32(offsets)
         buf = np.frombuffer(encoded, dtype=np.uint8)
@@ -105,7 +105,7 @@ class RansDecoder:
                                                     offs.ctypes.data, out.ctypes.data)
         if rc != 0:
             raise RuntimeError(f'oracle decode failed rc={rc}')
-        return out.tolist()
+        return out if as_array else out.tolist()
 
 
 # ------------------------------------------------------------------ compressai.ops.LowerBound
@@ -166,10 +166,19 @@ class EntropyModel(nn.Module):
             cdf[i, : _cdf.size(0)] = _cdf
         return cdf
 
+    # array_io = True: tensors go to the C coder as numpy arrays instead of through CompressAI's Python-list interface (what the
+    # reference really pays per call: .tolist() of every symbol).  Same bytes; used by bench.py's cpu_baseline so that the timed
+    # host baseline is not handicapped by list conversions.
+    array_io = False
+
     def compress(self, inputs, indexes, means=None):
         symbols = self.quantize(inputs, 'symbols', means)
         assert inputs.dim() >= 2 and inputs.size() == indexes.size()
         assert self._quantized_cdf.numel() > 0, 'Uninitialized CDFs. Run update() first'
+        if self.array_io:
+            cdf, sizes, offs = self._quantized_cdf.numpy(), self._cdf_length.reshape(-1).int().numpy(), self._offset.reshape(-1).int().numpy()
+            return [self._encoder.encode_with_indexes(symbols[i].reshape(-1).int().numpy(), indexes[i].reshape(-1).int().numpy(),
+                                                      cdf, sizes, offs) for i in range(symbols.size(0))]
         cdf, sizes, offs = self._quantized_cdf.tolist(), self._cdf_length.reshape(-1).int().tolist(), \
             self._offset.reshape(-1).int().tolist()
         strings = []
@@ -183,6 +192,12 @@ class EntropyModel(nn.Module):
         assert self._quantized_cdf.numel() > 0, 'Uninitialized CDFs. Run update() first'
         cdf = self._quantized_cdf
         outputs = cdf.new_empty(indexes.size())
+        if self.array_io:
+            cdfn, sizes, offs = cdf.numpy(), self._cdf_length.reshape(-1).int().numpy(), self._offset.reshape(-1).int().numpy()
+            for i, s in enumerate(strings):
+                values = self._decoder.decode_with_indexes(s, indexes[i].reshape(-1).int().numpy(), cdfn, sizes, offs, as_array=True)
+                outputs[i] = torch.from_numpy(values).reshape(outputs[i].size())
+            return self.dequantize(outputs, means, dtype)
         cdfl, sizes, offs = cdf.tolist(), self._cdf_length.reshape(-1).int().tolist(), \
             self._offset.reshape(-1).int().tolist()
         for i, s in enumerate(strings):

@@ -1,0 +1,261 @@
+"""-m gpu: the reduced-precision mode of BASELINE.json configs[4] ("bf16 activations + fp8 MFMA for 1x1 convs, tolerance-checked
+PSNR"): kernels against an exact emulation of their arithmetic (OCP MX-fp8 operands = e4m3 + one power-of-two scale per 32 k,
+fp32 accumulate, bf16 storage), then the model at 4 x 1216x1216 (1200x1200 padded): round trip exact IN the mode, batch == single,
+PSNR / bpp within a stated tolerance of the fp32-class path.  This is NOT a parity path (the parity bars live in test_gpu_model.py).
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import seeded_init
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    from lvae import _native
+    return _native.lib()
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _mx(t):
+    """What the MX-fp8 quantiser turns a [rows][K] fp32 matrix into (dequantised, fp32)."""
+    from lvae.models.base import pack_mxfp8, unpack_mxfp8
+    return unpack_mxfp8(pack_mxfp8(t.float().cpu()), t.shape[0], t.shape[1])
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _gemm(L, **kw):
+    from lvae._native import GemmDesc
+    d = GemmDesc()
+    keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    d.prec = 3
+    rc = L.lvae_gemm_f32(ctypes.byref(d), _st())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 384, 192), (1000, 192, 384), (129, 64, 512), (257, 448, 256), (96, 1024, 512), (2050, 128, 200)])
+@pytest.mark.parametrize('a_bf16,out_bf16,epi', [(1, 1, 1), (1, 1, 2), (1, 0, 0), (0, 1, 3), (0, 0, 0)])
+def test_gemm_mxfp8_matches_emulation(L, M, N, K, a_bf16, out_bf16, epi):
+    from lvae.models.base import pack_mxfp8
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))          # rows of very different magnitude
+    A[3, :40] = 0                                                                            # an all-zero MX block
+    if a_bf16:
+        A = _bf(A).float()
+    Wt = torch.randn(N, K, generator=g) / K ** 0.5
+    bias, gamma = torch.randn(N, generator=g), torch.rand(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    if out_bf16:
+        res = _bf(res).float()
+    ref = _mx(A).double() @ _mx(Wt).double().t() + bias.double()
+    ref = {0: ref, 1: F.gelu(ref), 2: res.double() + gamma.double() * ref, 3: res.double() + ref}[epi]
+    Ad = (_bf(A) if a_bf16 else A).cuda()
+    resd = (_bf(res) if out_bf16 else res).cuda()
+    out = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    Kp = (K + 63) // 64 * 64
+    _gemm(L, A0=Ad, lda0=K, K0=K, Wt16=pack_mxfp8(Wt).cuda(), ldw=Kp, bias=bias.cuda(), gamma=gamma.cuda(), res=resd, ldres=N, out=out,
+          ldo=N, M=M, N=N, K=K, epi=epi, a_bf16=a_bf16, out_bf16=out_bf16)
+    err = (out.double().cpu() - ref).abs()
+    scale = (_mx(A).abs().double() @ _mx(Wt).abs().double().t()) + ref.abs() + 1.0
+    # bf16 output rounding; with an fp32 output what is left is the matrix pipe's own accumulation of the 64 scaled fp8 products
+    # of a step, which is coarser than an fp32 fmaf chain (measured: up to 1.1e-5 of sum|a||w|; element quantisation itself is exact:
+    # a single e4m3 rounding mismatch would show as ~3e-4)
+    tol = (2.0 ** -8 if out_bf16 else 4e-5)
+    assert float((err / scale).max()) <= tol, float((err / scale).max())
+    # rows of a smaller call are bit-identical (nothing depends on M): the property that keeps encoder and decoder priors equal
+    half = M // 2
+    out2 = torch.full((half, N), float('nan'), device='cuda', dtype=out.dtype)
+    _gemm(L, A0=Ad, lda0=K, K0=K, Wt16=pack_mxfp8(Wt).cuda(), ldw=Kp, bias=bias.cuda(), gamma=gamma.cuda(), res=resd, ldres=N, out=out2,
+          ldo=N, M=half, N=N, K=K, epi=epi, a_bf16=a_bf16, out_bf16=out_bf16)
+    assert torch.equal(out2, out[:half])
+
+
+def test_gemm_mxfp8_gathers_and_stores(L):
+    """Fused torch.cat operand, 2x2 patch gather, 3x3 tap gather, PixelShuffle store and the final clamped NCHW image store."""
+    from lvae.models.base import pack_mxfp8
+    g = torch.Generator().manual_seed(11)
+    # concat [A0 | A1]
+    M, K0, K1, N = 500, 256, 384, 256
+    A0, A1 = _bf(torch.randn(M, K0, generator=g)), _bf(torch.randn(M, K1, generator=g))
+    Wt = torch.randn(N, K0 + K1, generator=g) / 25
+    b = torch.randn(N, generator=g)
+    out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    _gemm(L, A0=A0.cuda(), lda0=K0, K0=K0, A1=A1.cuda(), lda1=K1, K1=K1, Wt16=pack_mxfp8(Wt).cuda(), ldw=640, bias=b.cuda(), out=out, ldo=N,
+          M=M, N=N, K=K0 + K1, a_bf16=1, out_bf16=1)
+    ref = _mx(torch.cat([A0, A1], 1).float()).double() @ _mx(Wt).double().t() + b.double()
+    assert float(((out.double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 2.0 ** -8
+    # 2x2 / stride-2 patch conv: every 32-block of the gathered row lies inside one source pixel (Cin % 32 == 0)
+    B, H, W, Cin, Cout = 2, 6, 10, 64, 128
+    x = _bf(torch.randn(B, 2 * H, 2 * W, Cin, generator=g))
+    w = torch.randn(Cout, Cin, 2, 2, generator=g) / 16
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    rows = x.float().view(B, H, 2, W, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, 4 * Cin)
+    ref = _mx(rows).double() @ _mx(Wp).double().t()
+    out = torch.empty(B * H * W, Cout, device='cuda', dtype=torch.bfloat16)
+    _gemm(L, A0=x.cuda(), K0=Cin, H=H, W=W, Wt16=pack_mxfp8(Wp).cuda(), ldw=4 * Cin, out=out, ldo=Cout, M=B * H * W, N=Cout, K=4 * Cin,
+          a_mode=1, a_bf16=1, out_bf16=1)
+    assert float(((out.double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 2.0 ** -8
+    # 3x3 / pad-1 head with an fp32 output
+    B, H, W, Cin, z = 2, 5, 7, 64, 32
+    x = _bf(torch.randn(B, H, W, Cin, generator=g))
+    w = torch.randn(z, Cin, 3, 3, generator=g) / 24
+    Wp = w.permute(0, 2, 3, 1).reshape(z, -1).contiguous()
+    cols = F.unfold(x.float().permute(0, 3, 1, 2), 3, padding=1).view(B, Cin, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * Cin)
+    ref = _mx(cols).double() @ _mx(Wp).double().t()
+    out = torch.empty(B * H * W, z, device='cuda')
+    _gemm(L, A0=x.cuda(), K0=Cin, H=H, W=W, Wt16=pack_mxfp8(Wp).cuda(), ldw=9 * Cin, out=out, ldo=z, M=B * H * W, N=z, K=9 * Cin,
+          a_mode=2, a_bf16=1, out_bf16=0)
+    assert float(((out.double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 2e-4
+    # PixelShuffle store (bf16 NHWC) and the final image store (fp32 NCHW, clamped to [0, 1])
+    B, H, W, C, r, Co = 2, 4, 6, 128, 2, 64
+    f = _bf(torch.randn(B * H * W, C, generator=g))
+    Wt = torch.randn(Co * r * r, C, generator=g) / 11
+    ref = (_mx(f.float()).double() @ _mx(Wt).double().t()).view(B, H, W, r, r, Co).permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, Co)
+    out = torch.empty(B, H * r, W * r, Co, device='cuda', dtype=torch.bfloat16)
+    _gemm(L, A0=f.cuda(), lda0=C, K0=C, Wt16=pack_mxfp8(Wt).cuda(), ldw=C, out=out, ldo=Co * r * r, M=B * H * W, N=Co * r * r, K=C, store=2, r=r,
+          H=H, W=W, a_bf16=1, out_bf16=1)
+    assert float(((out.double().cpu() - ref).abs() / (ref.abs() + 1)).max()) <= 2.0 ** -8
+    r, Co = 4, 3
+    Wt = torch.randn(Co * r * r, C, generator=g) / 11
+    y = _mx(f.float()).double() @ _mx(Wt).double().t()                       # columns n = c*r^2 + i*r + j
+    ref = y.view(B, H, W, Co, r, r).permute(0, 3, 1, 4, 2, 5).reshape(B, Co, H * r, W * r).clamp(-1, 1) * 0.5 + 0.5
+    out = torch.empty(B, Co, H * r, W * r, device='cuda')
+    _gemm(L, A0=f.cuda(), lda0=C, K0=C, Wt16=pack_mxfp8(Wt).cuda(), ldw=C, out=out, ldo=Co * r * r, M=B * H * W, N=Co * r * r, K=C, store=3, r=r,
+          H=H, W=W, a_bf16=1, out_bf16=0)
+    assert float((out.double().cpu() - ref).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize('C,k,H,W', [(192, 7, 20, 33), (128, 7, 9, 11), (384, 5, 12, 10), (512, 3, 8, 12), (256, 7, 16, 8), (512, 1, 3, 4)])
+def test_dwconv_ln_bf16(L, C, k, H, W):
+    """bf16 in / bf16 out depthwise + LayerNorm + AdaLN == the fp32 kernel on the same (bf16-representable) input, rounded once."""
+    g = torch.Generator().manual_seed(C + k + H)
+    B = 2
+    x = _bf(torch.randn(B, H, W, C, generator=g)).cuda()
+    wp = (torch.randn(k * k, C, generator=g) / k).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    shift, sc1 = torch.randn(C, generator=g).cuda(), (1 + 0.3 * torch.randn(C, generator=g)).cuda()
+    y32 = torch.empty(B, H, W, C, device='cuda')
+    xf = x.float().contiguous()
+    assert L.lvae_dwconv_ln_f32(xf.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, shift.data_ptr(), sc1.data_ptr(), y32.data_ptr(),
+                                B, H, W, C, k, _st()) == 0
+    y16 = torch.empty(B, H, W, C, device='cuda', dtype=torch.bfloat16)
+    assert L.lvae_dwconv_ln_bf16(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, shift.data_ptr(), sc1.data_ptr(), y16.data_ptr(),
+                                 B, H, W, C, k, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+
+
+def test_stem_and_bias_expand_bf16(L):
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cout = 2, 24, 40, 192
+    im = torch.rand(B, 3, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 4, 4, generator=g) / 7).cuda()
+    wt = w.reshape(Cout, 48).t().contiguous()
+    b = torch.randn(Cout, generator=g).cuda()
+    o32 = torch.empty(B, H // 4, W // 4, Cout, device='cuda')
+    o16 = torch.empty(B, H // 4, W // 4, Cout, device='cuda', dtype=torch.bfloat16)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert L.lvae_stem_f32(im.data_ptr(), wt.data_ptr(), b.data_ptr(), o32.data_ptr(), B, H, W, Cout, -0.45, 3.6, None, _st()) == 0
+    assert L.lvae_stem_bf16(im.data_ptr(), wt.data_ptr(), b.data_ptr(), o16.data_ptr(), B, H, W, Cout, -0.45, 3.6, flag.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o32.to(torch.bfloat16)) and int(flag.item()) == 0
+    out = torch.empty(37, Cout, device='cuda', dtype=torch.bfloat16)
+    assert L.lvae_bias_expand_bf16(b.data_ptr(), out.data_ptr(), 37, Cout, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, b.to(torch.bfloat16).expand(37, Cout))
+
+
+# ------------------------------------------------------------------------------------------------ the model in this mode
+@pytest.fixture(scope='module')
+def typical_model():
+    """qarv_base with the 'typical' seeded weights (2.5 bpp like a trained model at lambda = 2048; the 'wide' profile of the parity
+    tests saturates the coder with escapes and says little about a rate tolerance)."""
+    import lvae
+    m = lvae.get_model('qarv_base')
+    sd = m.state_dict()
+    for k in list(sd):
+        a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0, profile='typical')
+        if a is not None:
+            sd[k] = torch.from_numpy(a)
+    m.load_state_dict(sd)
+    m = m.to('cuda:0').eval()
+    m.compress_mode()
+    return m
+
+
+def _psnr(a, b):
+    return -10 * math.log10(float((a - b).square().mean()))
+
+
+def test_config5_tecnick_1216x1216_fp8_mode(typical_model):
+    """BASELINE.json configs[4]: 1200x1200 images (padded to 1216x1216), batch of 4, bf16 activation storage + MX-fp8 GEMMs.
+    Stated tolerances against the fp32-class (bf16x3) path on the same images: |dPSNR| <= 0.5 dB, |d bpp| <= 5 %; inside the mode the
+    coder is lossless on the quantised latents (decompress(compress(x)) == the coder-free path), batch == single, deterministic."""
+    from lvae.utils.coding import pad_divisible_by, pil_to_tensor01
+    from PIL import Image
+    m = typical_model
+    ims = torch.stack([pil_to_tensor01(pad_divisible_by(Image.fromarray(seeded_init.synthetic_image_u8(1200, 1200, 900 + i)), 64))
+                       for i in range(4)]).cuda()
+    assert ims.shape == (4, 3, 1216, 1216)
+    lmb = 512.0
+    try:
+        m.set_gemm_precision('bf16x3')
+        s_ref = m.compress_batch(ims, lmb)
+        x_ref = m.decompress_batch(s_ref)
+        m.set_gemm_precision('fp8')
+        s8 = m.compress_batch(ims, lmb)
+        x8 = m.decompress_batch(s8)
+        xe, nats = m.estimate(ims, lmb)
+        assert torch.equal(x8, xe)                                   # round trip exact in-mode
+        assert s8 == m.compress_batch(ims, lmb)                      # deterministic
+        assert s8[2] == m.compress(ims[2:3], lmb)                    # batch == single (per-row quantisation, fixed k order)
+        assert torch.equal(m.decompress(s8[2]), x8[2:3])
+        p_ref, p8 = _psnr(x_ref, ims), _psnr(x8, ims)
+        b_ref = np.mean([len(s) for s in s_ref]) * 8 / (1216 * 1216)
+        b8 = np.mean([len(s) for s in s8]) * 8 / (1216 * 1216)
+        print(f'config 5: PSNR fp32-class {p_ref:.3f} dB, fp8 mode {p8:.3f} dB; bpp {b_ref:.4f} vs {b8:.4f}; '
+              f'PSNR(fp8 recon vs fp32-class recon) {_psnr(x8, x_ref):.2f} dB')
+        assert abs(p8 - p_ref) <= 0.5 and abs(b8 - b_ref) <= 0.05 * b_ref
+        # a stream of one mode must not be decoded in another one: the arithmetic is part of the stream's contract
+        m.set_gemm_precision('bf16x3')
+        try:
+            bad = m.decompress_batch(s8)
+            assert not torch.equal(bad, x8)
+        except (ValueError, RuntimeError):
+            pass
+    finally:
+        m.set_gemm_precision('bf16x3')
+
+
+def test_fp8_mode_small_images_and_estimate(typical_model):
+    m = typical_model
+    try:
+        m.set_gemm_precision('fp8')
+        im = torch.from_numpy(seeded_init.synthetic_image_u8(128, 192, 3)).permute(2, 0, 1).float().div(255).unsqueeze(0).cuda()
+        for lmb in (64.0, 2048.0):
+            s = m.compress(im, lmb)
+            x = m.decompress(s)
+            xe, nats = m.estimate(im, lmb)
+            assert torch.equal(x, xe) and x.shape == im.shape
+            bits = float(nats.sum()) / math.log(2)
+            assert 0.6 * bits < len(s) * 8 < 1.1 * bits + 800
+    finally:
+        m.set_gemm_precision('bf16x3')
