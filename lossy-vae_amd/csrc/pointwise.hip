@@ -325,6 +325,223 @@ __global__ __launch_bounds__(512, 1) void dwconv_ln_tile_kernel(const float* __r
     }
 }
 
+// Second-generation tiled form ("t2"): the same operator for every C = 64 NV layer on maps with enough tiles to fill the chip, fp32
+// or bf16 storage.  What the PMC counters said about dwconv_ln_tile_kernel (B = 8, 128x192, C = 192: 127 us): its 2048 waves are
+// parked 40 % of their cycles (s_waitcnt / barrier) and issue-stalled another 23 %, VALU-active 25 %, LDS array 32 % busy -- one
+// 512-thread workgroup per CU (116 KB of LDS) runs its phases [barrier, registers -> LDS, barrier, prefetch, taps] one after the
+// other and nothing else is resident to fill the gaps.  Here a workgroup is 256 threads on a 4 x 16 pixel tile and keeps only ONE
+// channel chunk's halo tile + weights in LDS (69 KB at k = 7, 47 KB at k = 5): two to three workgroups share a CU and overlap each
+// other's staging, barriers and global-load latency; the taps are explicit packed FMAs (v_pk_fma_f32, half the VALU issue slots;
+// each component is an fmaf, so the bits do not change).  16 lanes own a pixel group (4 pixels x all channels, chunk c of lane cl =
+// channels 4 (cl + 16 c) ..+3); the LayerNorm sums are formed in exactly the association of dwconv_ln_kernel's <.., LPP = RL, ..>
+// instance for this C (RL = 32: the first butterfly step, lane ^ 16, happens inside the lane), so all three kernels give the same
+// bits and the launcher may choose by map size.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int KS, int NV, int RL, bool BF>
+__global__ __launch_bounds__(256, 2) void dwconv_ln_t2_kernel(const void* __restrict__ x, const float* __restrict__ wt,
+                                                              const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, const float* __restrict__ shift,
+                                                              const float* __restrict__ scale1p, void* __restrict__ y,
+                                                              int B, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int LPP = 16, TW = 4, GX = 4, TBW = 16, TBH = 4, PGB = 16;
+    constexpr int C = 64 * NV;
+    constexpr int P = (KS - 1) / 2, LW = TBW + KS - 1, LH = TBH + KS - 1, NPIX = LW * LH, KK = KS * KS;
+    constexpr int NF = (NPIX + PGB - 1) / PGB;                       // staged pixels per thread per chunk
+    constexpr int NWF = (KK + PGB - 1) / PGB;                        // staged weight taps per thread per chunk
+    static_assert(RL == 16 || (RL == 32 && NV % 2 == 0), "reference lane count");
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    f32x4* tile = (f32x4*)dw_lds;                                   // [NPIX][16]
+    f32x4* wl = tile + NPIX * LPP;                                  // [KK][16]
+    const int tid = threadIdx.x, cl = tid % LPP, pg = tid / LPP;
+    const int gy = pg / GX, gx = pg % GX;
+    const int nb = gridDim.x, bq = nb / 8, br = nb % 8, xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    const int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + loc;
+    const int per = n_tiles / nb, rem = n_tiles % nb;
+    const int t_begin = bid * per + (bid < rem ? bid : rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
+
+    f32x4 st[NF], sw[NWF];
+    unsigned inmask = 0;
+    auto prefetch = [&](int t, int v) {                              // global -> registers, branch-free (clamped address + mask)
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        const long b = t / (tiles_x * tiles_y);
+        const long xb = b * (long)H * W * C + 4 * (cl + v * LPP);
+        const int h0 = ty * TBH - P, w0 = tx * TBW - P;
+        inmask = 0;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int pix = pg + PGB * n, ly = pix / LW, lx = pix - ly * LW;     // halo-tile coordinates (recomputed: registers are scarce)
+            const int hh = h0 + ly, ww = w0 + lx;
+            const bool in = pix < NPIX && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            inmask |= (in ? 1u : 0u) << n;
+            st[n] = ld4<BF>(x, xb + (in ? ((long)hh * W + ww) * C : 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NWF; ++n) {
+            const int tap = pg + PGB * n;
+            sw[n] = *(const f32x4*)(wt + (long)(tap < KK ? tap : 0) * C + 4 * (cl + v * LPP));
+        }
+    };
+    auto commit = [&]() {                                            // registers -> LDS
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+            if (pg + PGB * n < NPIX) tile[(pg + PGB * n) * LPP + cl] = ((inmask >> n) & 1u) ? st[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NWF; ++n)
+            if (pg + PGB * n < KK) wl[(pg + PGB * n) * LPP + cl] = sw[n];
+    };
+
+    if (t_begin < t_end) prefetch(t_begin, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        const long b = t / (tiles_x * tiles_y);
+        const int h0 = ty * TBH, w0 = tx * TBW;
+        f32x4 acc[NV][TW];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            __syncthreads();                                         // previous chunk's readers are done
+            commit();
+            __syncthreads();
+            if (v + 1 < NV) prefetch(t, v + 1);
+            else if (t + 1 < t_end) prefetch(t + 1, 0);
+            const f32x4 bv = *(const f32x4*)(bias + 4 * (cl + v * LPP));
+#pragma unroll
+            for (int q = 0; q < TW; ++q) acc[v][q] = bv;
+#pragma unroll 1
+            for (int i = 0; i < KS; ++i) {
+                const f32x4* row = tile + ((gy + i) * LW + gx * TW) * LPP + cl;
+                const f32x4* wrow = wl + (i * KS) * LPP + cl;
+                f32x4 xr[TW + KS - 1];
+#pragma unroll
+                for (int q = 0; q < TW + KS - 1; ++q) xr[q] = row[q * LPP];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const f32x4 wv = wrow[j * LPP];
+#pragma unroll
+                    for (int q = 0; q < TW; ++q) acc[v][q] = __builtin_elementwise_fma(xr[q + j], wv, acc[v][q]);
+                }
+            }
+        }
+        const float inv_c = 1.0f / (float)C;
+        const int hh = h0 + gy;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            // per-lane partial sums in the reference kernel's order: lane c of its RL lanes adds its chunks c, c + RL, c + 2 RL, ...
+            float s;
+            if (RL == 16) {
+                s = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
+            } else {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; v += 2) {
+                    sa += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
+                    sb += (acc[v + 1][q][0] + acc[v + 1][q][1]) + (acc[v + 1][q][2] + acc[v + 1][q][3]);
+                }
+                s = sa + sb;                                         // the reference's lane ^ 16 step
+            }
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * inv_c;
+            float sq;
+            if (RL == 16) {
+                sq = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = acc[v][q][e] - mean;
+                        acc[v][q][e] = dlt;
+                        sq = fmaf(dlt, dlt, sq);
+                    }
+                }
+            } else {
+                float qa = 0.f, qb = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; v += 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float da = acc[v][q][e] - mean, db = acc[v + 1][q][e] - mean;
+                        acc[v][q][e] = da; acc[v + 1][q][e] = db;
+                        qa = fmaf(da, da, qa);
+                        qb = fmaf(db, db, qb);
+                    }
+                }
+                sq = qa + qb;
+            }
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
+            const int ww = w0 + gx * TW + q;
+            if (ww < W && hh < H) {
+                const long yp = ((b * H + hh) * (long)W + ww) * C;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int c = 4 * (cl + v * LPP);
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][q][e] * rstd;
+                    if (ln_w) {
+                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
+                    }
+                    if (shift) {
+                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
+                    }
+                    st4<BF>(y, yp + c, o4);
+                }
+            }
+        }
+    }
+}
+
+int g_dw_t2 = -1;      // tuning hook (LVAE_DW_T2): 0 = never, 1 = whenever an instance exists, -1 = heuristic
+
+template <int KS, int NV, int RL, bool BF>
+int launch_dwln_t2(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                   const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
+    constexpr int NPIX = (16 + KS - 1) * (4 + KS - 1), LDS = (NPIX + KS * KS) * 256;
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv_ln_t2_kernel<KS, NV, RL, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 3) / 4;
+    const long n_tiles = (long)B * tiles_x * tiles_y;
+    const int per_cu = (160 * 1024) / LDS < 4 ? (160 * 1024) / LDS : 4;
+    const long cap = 256L * per_cu;
+    const int grid = (int)(n_tiles < cap ? n_tiles : cap);
+    hipLaunchKernelGGL((dwconv_ln_t2_kernel<KS, NV, RL, BF>), dim3(grid), dim3(256), LDS, st, x, wt, bias, ln_w, ln_b, shift, scale1p, y,
+                       B, H, W, tiles_x, tiles_y, (int)n_tiles);
+    return (int)hipGetLastError();
+}
+
+// t2 is taken when the map has at least ~1.5 tiles per CU (below that the register sliding-window kernel's finer granularity wins)
+template <int KS, bool BF>
+int try_dwln_t2(int C, const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
+                const float* scale1p, void* y, int B, int H, int W, hipStream_t st, int* rc) {
+    if constexpr (KS >= 3) {
+        const long n_tiles = (long)B * ((W + 15) / 16) * ((H + 3) / 4);
+        // fp32 maps: measured no faster than dwconv_ln_tile_kernel / the sliding-window kernel (B = 8, 128x192, C = 192: 172 vs 134 us --
+        // its 4 x 16 tiles stage 3.4 halo pixels per output pixel against 2.4 for the 8 x 16 tiles), so it is taken for bf16 maps only,
+        // where it replaces the 8-byte-per-lane sliding-window loads (257 -> 140 us); LVAE_DW_T2=1 forces it for experiments
+        if (g_dw_t2 == 0 || (g_dw_t2 < 0 && (!BF || n_tiles < 384))) return 0;
+        switch (C) {
+            case 128: *rc = launch_dwln_t2<KS, 2, 16, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
+            case 192: *rc = launch_dwln_t2<KS, 3, 16, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
+            case 256: *rc = launch_dwln_t2<KS, 4, 32, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
+            case 384: *rc = launch_dwln_t2<KS, 6, 32, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
+        }
+    }
+    return 0;
+}
+
 int g_dw_tile = -1;    // tuning hook (LVAE_DW_TILE): 0 = never, 1 = whenever an instance exists, -1 = heuristic
 
 template <int KS, int VPL>
@@ -695,6 +912,17 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
         env_read = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    {
+        const char* e = nullptr;
+        static bool t2_read = false;
+        if (!t2_read) { e = getenv("LVAE_DW_T2"); if (e) g_dw_t2 = atoi(e); t2_read = true; }
+        int rc = 0;
+        if (g_dw_tile != 1 && g_dw_th == 0) {
+            if (k == 3 && try_dwln_t2<3, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+            if (k == 5 && try_dwln_t2<5, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+            if (k == 7 && try_dwln_t2<7, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+        }
+    }
     switch (k) {
         case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 3: return dispatch_dwln_c<3>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -728,6 +956,14 @@ extern "C" int lvae_dwconv_ln_bf16(const void* x, const float* wt, const float* 
     if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
     if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
     hipStream_t st = (hipStream_t)stream;
+    {
+        static bool t2_read = false;
+        if (!t2_read) { const char* e = getenv("LVAE_DW_T2"); if (e) g_dw_t2 = atoi(e); t2_read = true; }
+        int rc = 0;
+        if (k == 3 && try_dwln_t2<3, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+        if (k == 5 && try_dwln_t2<5, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+        if (k == 7 && try_dwln_t2<7, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
+    }
     switch (k) {
         case 1: return dispatch_dwln_bf16<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 3: return dispatch_dwln_bf16<3>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
