@@ -230,6 +230,10 @@ int lvae_bias_expand_f32(const float* bias, float* out, long M, int C, void* str
 /* sum over all elements of (a-b)^2 per image into out[b] (double), for PSNR (lvae/evaluation.py:47-49);
  * out must be zeroed by the caller. */
 int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, int B, long n_per_image, void* stream);
+/* Deterministic form for ONE image pair of n floats: block i of n_partials writes partials[i] = its share of sum((a-b)^2) in fp64
+ * (fixed element -> thread map, no atomics); the caller adds the partials in index order.  Run-to-run and process-to-process
+ * identical, which the sharded evaluation needs to reproduce the single-process means bit for bit. */
+int lvae_sqerr_partials_f32(const float* a, const float* b, double* partials, int n_partials, long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1064,6 +1064,30 @@ extern "C" int lvae_bias_expand_f32(const float* bias, float* out, long M, int C
     return (int)hipGetLastError();
 }
 
+namespace {
+// deterministic form: block i writes its own partial sum (fixed thread -> element map, fixed in-block order, no atomics)
+__global__ __launch_bounds__(256) void sqerr_partials_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             double* __restrict__ partials, long n) {
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float dlt = a[i] - b[i];
+        s += (double)dlt * (double)dlt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+}  // namespace
+
+extern "C" int lvae_sqerr_partials_f32(const float* a, const float* b, double* partials, int n_partials, long n, void* stream) {
+    if (!a || !b || !partials || n_partials <= 0 || n <= 0) return -22;
+    hipLaunchKernelGGL(sqerr_partials_kernel, dim3((unsigned)n_partials), dim3(256), 0, (hipStream_t)stream, a, b, partials, n);
+    return (int)hipGetLastError();
+}
+
 extern "C" int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, int B, long n_per_image, void* stream) {
     if (!a || !b || !out || B <= 0 || n_per_image <= 0) return -22;
     long bx = (n_per_image + 256 * 8 - 1) / (256 * 8);
@@ -1110,5 +1134,5 @@ extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 11; }
+extern "C" int lvae_abi_version(void) { return 12; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 
@@ -63,6 +63,7 @@ SIGNATURES = {
     'lvae_gaussian_nll_f32': (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+    'lvae_sqerr_partials_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
 }
 
 

@@ -23,15 +23,38 @@ def _list_images(dataset):
     return img_paths
 
 
+def _mse(real, fake):
+    """mean((real - fake)^2) of one image (evaluation.py:47-49).  On the GPU: the native fp64-accumulating reduction
+    (lvae_sqerr_partials_f32: deterministic) on the decoder's output where it lies -- no 12 B/pixel device-to-host copy and CPU pass per image;
+    CPU tensors (stub codecs in tests): the reference's expression.  Every caller goes through here, so the sharded and the
+    single-process evaluations agree bit for bit."""
+    fake = fake.squeeze(0)
+    if fake.is_cuda:
+        import ctypes
+        from . import _native
+        a = fake.contiguous()
+        b = real.to(a.device, non_blocking=True).contiguous()
+        nblk = 512
+        out = torch.empty(nblk, dtype=torch.float64, device=a.device)
+        with torch.cuda.device(a.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+            _native.check(_native.lib().lvae_sqerr_partials_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), nblk, a.numel(), st), 'sqerr')
+        total = 0.0
+        for v in out.cpu().tolist():          # fixed order: deterministic across runs and processes
+            total += v
+        return total / a.numel()
+    return (real - fake.cpu()).square().mean().item()
+
+
 def _eval_one(model, impath, tmp_bits_dir, tag=''):
     from PIL import Image
     tmp_bits_path = tmp_bits_dir / f'{impath.stem}{tag}.bits'
     model.compress_file(impath, tmp_bits_path)
     num_bits = tmp_bits_path.stat().st_size * 8
-    fake = model.decompress_file(tmp_bits_path).squeeze(0).cpu()
+    fake = model.decompress_file(tmp_bits_path)
     tmp_bits_path.unlink()
     real = pil_to_tensor01(Image.open(impath))
-    mse = (real - fake).square().mean().item()
+    mse = _mse(real, fake)
     return {'bpp': float(num_bits / float(real.shape[1] * real.shape[2])), 'mse': float(mse),
             'psnr': float(-10 * math.log10(mse))}
 
@@ -96,20 +119,32 @@ def batch_same_size(indices, shapes, max_batch=8, max_pixels=8 * 512 * 768 * 4):
     return out
 
 
-def _eval_batch(model, paths, tmp_bits_dir, tag=''):
-    """_eval_one for a batch of same-padded-size images through the model's batched file API (bit-identical per image)."""
+def _decode_images(paths):
+    """PIL images of `paths`, fully decoded (run on a helper thread: PNG decoding releases the GIL)."""
     from PIL import Image
-    if len(paths) == 1 or not hasattr(model, 'compress_files'):
+    imgs = []
+    for p in paths:
+        img = Image.open(p)
+        img.load()
+        imgs.append(img)
+    return imgs
+
+
+def _eval_batch(model, paths, tmp_bits_dir, tag='', images=None):
+    """_eval_one for a batch of same-padded-size images through the model's batched file API (bit-identical per image); every
+    PNG is decoded once (`images`: already decoded by the prefetch thread)."""
+    if not hasattr(model, 'compress_files'):
         return [_eval_one(model, p, tmp_bits_dir, tag) for p in paths]
+    imgs = images if images is not None else _decode_images(paths)
     bits = [tmp_bits_dir / f'{p.stem}{tag}.{k}.bits' for k, p in enumerate(paths)]
-    model.compress_files(paths, bits)
+    model.compress_files(paths, bits, images=imgs)
     fakes = model.decompress_files(bits)
     out = []
-    for p, b, fake in zip(paths, bits, fakes):
+    for img, b, fake in zip(imgs, bits, fakes):
         num_bits = b.stat().st_size * 8
         b.unlink()
-        real = pil_to_tensor01(Image.open(p))
-        mse = (real - fake.squeeze(0).cpu()).square().mean().item()
+        real = pil_to_tensor01(img)
+        mse = _mse(real, fake)
         out.append({'bpp': float(num_bits / float(real.shape[1] * real.shape[2])), 'mse': float(mse),
                     'psnr': float(-10 * math.log10(mse))})
     return out
@@ -148,10 +183,18 @@ def imcoding_evaluate_sharded(model, dataset, partition='lpt', max_batch=8):
     else:
         mine = list(range(rank, len(img_paths), world))
     local = []
-    for batch in batch_same_size(mine, [m[1] for m in meta], max_batch=max_batch):
-        stats = _eval_batch(model, [img_paths[i] for i in batch], tmp_bits_dir, tag=f'.r{rank}')
-        for idx, s in zip(batch, stats):
-            local.append([float(idx), s['bpp'], s['mse'], s['psnr']])
+    batches = batch_same_size(mine, [m[1] for m in meta], max_batch=max_batch)
+    # the next batch's PNGs are decoded on a helper thread while the GPU and the coder threads work on the current one
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(_decode_images, [img_paths[i] for i in batches[0]]) if batches else None
+        for bi, batch in enumerate(batches):
+            imgs = nxt.result()
+            nxt = pool.submit(_decode_images, [img_paths[i] for i in batches[bi + 1]]) if bi + 1 < len(batches) else None
+            stats = _eval_batch(model, [img_paths[i] for i in batch], tmp_bits_dir, tag=f'.r{rank}',
+                                images=imgs if hasattr(model, 'compress_files') else None)
+            for idx, s in zip(batch, stats):
+                local.append([float(idx), s['bpp'], s['mse'], s['psnr']])
     dev = next(model.parameters()).device
     rows = gather_stats(local, world, dev if dist.get_backend() == 'nccl' else None)
     assert rows.shape[0] == len(img_paths)

@@ -683,11 +683,11 @@ class VariableRateLossyVAE(CodecBase):
         return im_hat[:, :, :img_h, :img_w]
 
     @torch.no_grad()
-    def compress_files(self, img_paths, output_paths, lmb=None):
+    def compress_files(self, img_paths, output_paths, lmb=None, images=None):
         """Batched compress_file: images whose PADDED sizes agree are coded by one compress_batch call (GPU work batched, the B x 9
         rANS streams coded in parallel); every output file is byte-identical to what compress_file writes for that image."""
         from PIL import Image
-        imgs = [Image.open(p) for p in img_paths]
+        imgs = images if images is not None else [Image.open(p) for p in img_paths]      # `images`: already decoded PIL images
         ims = [coding.pil_to_tensor01(coding.pad_divisible_by(img, div=self.max_stride)) for img in imgs]
         assert all(t.shape == ims[0].shape for t in ims), 'compress_files: padded sizes differ'
         bodies = self.compress_batch(torch.stack(ims).to(device=self._dummy.device), lmb=lmb)

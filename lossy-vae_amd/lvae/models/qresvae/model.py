@@ -637,10 +637,10 @@ class HierarchicalVAE(CodecBase):
         return self.decompress(obj)[:, :, :img_h, :img_w]
 
     @torch.no_grad()
-    def compress_files(self, img_paths, output_paths):
+    def compress_files(self, img_paths, output_paths, images=None):
         """Batched compress_file (same padded size): one compress_batch call; files identical to compress_file's."""
         from PIL import Image
-        imgs = [Image.open(p) for p in img_paths]
+        imgs = images if images is not None else [Image.open(p) for p in img_paths]      # `images`: already decoded PIL images
         ims = [coding.pil_to_tensor01(coding.pad_divisible_by(img, div=self.max_stride)) for img in imgs]
         assert all(t.shape == ims[0].shape for t in ims), 'compress_files: padded sizes differ'
         objs = self.compress_batch(torch.stack(ims).to(device=self._dummy.device))

@@ -11,6 +11,7 @@ import math
 import os
 import sys
 import tempfile
+import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'lossy-vae_amd'))
 import torch  # noqa: E402
@@ -30,6 +31,8 @@ def main():
     ap.add_argument('-s', '--steps', type=int, default=4)
     ap.add_argument('--synthetic', type=int, default=0)
     ap.add_argument('--backend', type=str, default='nccl')
+    ap.add_argument('--max-batch', type=int, default=8, help='same-size images coded per batch inside a rank (1 = one image at a time)')
+    ap.add_argument('--partition', type=str, default='lpt', choices=['lpt', 'stride'], help='LPT by padded pixels, or rank::world')
     args = ap.parse_args()
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
@@ -70,9 +73,14 @@ def main():
     for lmb in lambdas:
         if lmb is not None:
             model.default_lmb = lmb
-        res = imcoding_evaluate_sharded(model, dataset)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        res = imcoding_evaluate_sharded(model, dataset, partition=args.partition, max_batch=args.max_batch)
+        dt = time.time() - t0
         if rank == 0:
             print(f'lambda={lmb}: {res}', flush=True)
+            print(f'  [{world} rank(s), partition={args.partition}, max_batch={args.max_batch}] {dt:.2f} s for the set '
+                  f'(file reads, PNG decode, PSNR and the all_gather included)', flush=True)
     dist.destroy_process_group()
 
 
