@@ -199,8 +199,12 @@ def main():
     # the cores of its GPU's NUMA node (skipped when the node topology cannot be read or looks skewed), pool sized to the slice
     ncpu = None
     if world > 1 and os.environ.get('LVAE_BENCH_SINGLE_GPU_TEST') != '1':
-        from lvae.utils.numa import pin_ranks_collectively
-        ncpu = pin_ranks_collectively(local_rank, dist, local_rank, world)
+        try:
+            from lvae.utils.numa import pin_ranks_collectively
+            ncpu = pin_ranks_collectively(local_rank, dist, local_rank, world)
+        except Exception as e:                                  # placement is an optimisation: never lose the run over it
+            print(f'[rank {rank}] NUMA pinning skipped: {e!r}', file=sys.stderr)
+            ncpu = None
     if ncpu:
         model.coder_threads = max(4, ncpu)
     else:

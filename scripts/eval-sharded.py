@@ -42,7 +42,11 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group(args.backend, rank=rank, world_size=world)
     from lvae.utils.numa import pin_ranks_collectively
-    ncpu = None if os.environ.get('LVAE_SINGLE_GPU_TEST') == '1' else pin_ranks_collectively(local, dist, local, world)
+    try:
+        ncpu = None if os.environ.get('LVAE_SINGLE_GPU_TEST') == '1' else pin_ranks_collectively(local, dist, local, world)
+    except Exception as e:
+        print(f'[rank {rank}] NUMA pinning skipped: {e!r}', file=sys.stderr)
+        ncpu = None
     kwargs = eval(f'dict({args.model_args})')
     dataset = args.dataset_name
     if args.synthetic:
