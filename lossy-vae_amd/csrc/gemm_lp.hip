@@ -19,6 +19,8 @@
 //    residual rows have the output's type.
 #include "gemm_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -99,7 +101,7 @@ __device__ __forceinline__ void lp_quant8(const float (&v)[8], u32x2& packed, un
     const unsigned ab = __float_as_uint(am);
     int eb = (int)((ab >> 23) & 0xffu) - 8;                      // biased exponent of 2^(floor(log2 amax) - 8): amax / scale in [256, 512)
     if ((ab & 0x7fffffu) > 0x600000u) eb += 1;                   // mantissa > 1.75: would exceed e4m3's 448 -> one more step
-    eb = eb < 0 ? 0 : (eb > 254 ? 254 : eb);                     // E8M0: 2^(eb - 127); all-zero (or tiny) blocks get 2^-127
+    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);                     // E8M0: 2^(eb - 127); all-zero (or tiny) blocks get 2^-126
     const float inv = __uint_as_float((unsigned)(254 - eb) << 23);      // 2^(127 - eb), exact
     int w0 = 0, w1 = 0;
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w0, false);
@@ -108,6 +110,57 @@ __device__ __forceinline__ void lp_quant8(const float (&v)[8], u32x2& packed, un
     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, w1, true);
     packed[0] = (unsigned)w0; packed[1] = (unsigned)w1;
     scale_byte = (unsigned)eb;
+}
+
+// The same for 8 bf16 values as they come from HBM (4 packed dwords): magnitudes of bf16 compare like unsigned integers, so the block
+// amax is three v_pk_max_u16 and a quad DPP reduction on the bit patterns, and v_cvt_scalef32_pk_fp8_bf16 (fp8(src / scale), round to
+// nearest even; probed with tools/ubench/cvt_scale_probe.hip) unpacks, scales and converts two values per instruction: ~28 VALU
+// instructions per 8 values instead of ~50 -- the quantiser, not the MFMA, is what this kernel's waves spend their issue slots on
+// (PMC: 2 500 VALU instructions per wave against 24 MFMAs).  Same arithmetic as lp_quant8, so both give the same bytes.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lp_quant8_bf16(const u32x4& raw, u32x2& packed, unsigned& scale_byte) {
+    const u16x2 a0 = __builtin_bit_cast(u16x2, raw[0] & 0x7fff7fffu), a1 = __builtin_bit_cast(u16x2, raw[1] & 0x7fff7fffu);
+    const u16x2 a2 = __builtin_bit_cast(u16x2, raw[2] & 0x7fff7fffu), a3 = __builtin_bit_cast(u16x2, raw[3] & 0x7fff7fffu);
+    const u16x2 mm = __builtin_elementwise_max(__builtin_elementwise_max(a0, a1), __builtin_elementwise_max(a2, a3));
+    unsigned am = mm[0] > mm[1] ? (unsigned)mm[0] : (unsigned)mm[1];
+    {
+        const unsigned o1 = (unsigned)__builtin_amdgcn_mov_dpp((int)am, 0xB1, 0xF, 0xF, true);
+        am = am > o1 ? am : o1;
+        const unsigned o2 = (unsigned)__builtin_amdgcn_mov_dpp((int)am, 0x4E, 0xF, 0xF, true);
+        am = am > o2 ? am : o2;
+    }
+    int eb = (int)((am >> 7) & 0xffu) - 8;                       // bf16: exponent in bits 14..7, 7 mantissa bits
+    if ((am & 0x7fu) > 0x60u) eb += 1;                           // mantissa > 1.75 (same rule as lp_quant8 / pack_mxfp8)
+    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+    const float scale = __uint_as_float((unsigned)eb << 23);    // 2^(eb - 127)
+    // (inline asm: with the __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16 form hipcc 7.2 emitted both halves of a dword from the SAME
+    //  source register and dropped the second dword's conversions -- seen in the ISA and as wrong products on the GPU)
+    unsigned w0 = 0, w1 = 0;
+    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w0) : "v"(raw[0]), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w0) : "v"(raw[1]), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w1) : "v"(raw[2]), "v"(scale));
+    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w1) : "v"(raw[3]), "v"(scale));
+    packed[0] = w0; packed[1] = w1;
+    scale_byte = (unsigned)eb;
+}
+
+// GELU of the reduced-precision mode's fc1 epilogue: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 the
+// result is stored in) on v_rcp_f32 / v_exp_f32 -- ~16 VALU instructions per element instead of the ~28 of the < 1 ulp erf the
+// parity path needs.  Deterministic, and identical in encoder and decoder (both run this kernel).
+__device__ __forceinline__ float lp_gelu(float x) {
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float erfv = copysignf(erf_abs, z);
+    return 0.5f * x * (1.0f + erfv);
 }
 
 template <bool OBF>
@@ -163,76 +216,84 @@ __global__ __launch_bounds__(256, 2) void gemm_lp_kernel(const lvae_gemm_desc d,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    u32x4 ra[4][ABF ? 1 : 2];
-    unsigned okm = 0;
-    u32x4 rw[NW];
-    unsigned short rs = 0;
+    // Register staging, one k-step ahead (DEPTH = 1).  Deeper rings (2 and 3 steps in flight, branch-free so that hipcc's counted
+    // s_waitcnt vmcnt survive) were measured and bought nothing: the waves are not waiting for HBM but for each other at the
+    // per-step barrier while the quantiser competes for VALU issue (PMC: 2 500 VALU instructions per wave, 24 MFMAs).
+    constexpr int DEPTH = 1;
+    u32x4 ra[DEPTH][4][ABF ? 1 : 2];
+    unsigned okm[DEPTH];
+    u32x4 rw[DEPTH][NW];
+    unsigned short rs[DEPTH];
     const int nk = (d.K + 63) / 64;
 
-    auto gload = [&](int kt) {
+    // k-steps are issued for kt in [0, ceil(nk / DEPTH) * DEPTH): steps beyond the last real one re-read it (valid addresses) with
+    // their A flagged as zeros, so they add exactly 0 to the accumulators -- and the whole pipeline is BRANCH-FREE: with conditional
+    // loads hipcc's s_waitcnt vmcnt at the control-flow merges is the worst case over both paths, i.e. vmcnt(0) before every
+    // quantiser pass (PMC: waves parked 51 % of their cycles), which threw the ring's depth away.
+    auto gload = [&](auto set_tag, int kt_req) {
+        constexpr int S = decltype(set_tag)::value;
+        const bool real = kt_req < nk;
+        const int kt = real ? kt_req : nk - 1;
         const int k = kt * 64 + piece * 8;
-        okm = 0;
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool ok;
             const char* p = lp_addr<AMODE>(d, rows[j], k, esz, ok);
-            okm |= (ok ? 1u : 0u) << j;
-            ra[j][0] = *(const u32x4*)p;
-            if (!ABF) ra[j][1] = *(const u32x4*)(p + 16);
+            m |= ((ok && real) ? 1u : 0u) << j;
+            ra[S][j][0] = *(const u32x4*)p;
+            if (!ABF) ra[S][j][1] = *(const u32x4*)(p + 16);
         }
+        okm[S] = m;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int c = tid + 256 * j;
             int n = n0 + (c >> 2);
             n = n < d.N ? n : d.N - 1;
-            if (NWCH % 256 == 0 || c < NWCH) rw[j] = *(const u32x4*)(wq + (long)n * d.ldw + kt * 64 + (c & 3) * 16);
+            if (NWCH % 256 == 0 || c < NWCH) rw[S][j] = *(const u32x4*)(wq + (long)n * d.ldw + kt * 64 + (c & 3) * 16);
         }
         if (tid < BN) {
             int n = n0 + tid;
             n = n < d.N ? n : d.N - 1;
-            rs = *(const unsigned short*)(wsc + (long)n * nsc + kt * 2);
+            rs[S] = *(const unsigned short*)(wsc + (long)n * nsc + kt * 2);
         }
     };
-    auto lstore = [&](char* st) {
+    auto lstore = [&](auto set_tag, char* st) {
+        constexpr int S = decltype(set_tag)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v[8];
-            if (ABF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] = bf16_lo(ra[j][0][e]); v[2 * e + 1] = bf16_hi(ra[j][0][e]); }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ra[j][0][e]); v[4 + e] = __uint_as_float(ra[j][ABF ? 0 : 1][e]); }
-            }
-            const bool ok = (okm >> j) & 1u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
-            if (d.a_gelu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-            }
+            const bool ok = (okm[S] >> j) & 1u;
             u32x2 pk;
             unsigned sb;
-            lp_quant8(v, pk, sb);
+            if (ABF) {
+                u32x4 raw = ra[S][j][0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[e] = ok ? raw[e] : 0u;
+                lp_quant8_bf16(raw, pk, sb);
+            } else {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ra[S][j][0][e]); v[4 + e] = __uint_as_float(ra[S][j][ABF ? 0 : 1][e]); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
+                lp_quant8(v, pk, sb);
+            }
             const int row = (tid + 256 * j) >> 3;
             *(u32x2*)(st + row * LP_ROWB + piece * 8) = pk;
             if ((piece & 3) == 0) *(unsigned char*)(st + row * LP_ROWB + 64 + (piece >> 2)) = (unsigned char)sb;
+            __builtin_amdgcn_sched_barrier(0);           // one chunk's quantiser temporaries at a time (register pressure)
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int c = tid + 256 * j;
-            if (NWCH % 256 == 0 || c < NWCH) *(u32x4*)(st + (BM + (c >> 2)) * LP_ROWB + (c & 3) * 16) = rw[j];
+            if (NWCH % 256 == 0 || c < NWCH) *(u32x4*)(st + (BM + (c >> 2)) * LP_ROWB + (c & 3) * 16) = rw[S][j];
         }
-        if (tid < BN) *(unsigned short*)(st + (BM + tid) * LP_ROWB + 64) = rs;
+        if (tid < BN) *(unsigned short*)(st + (BM + tid) * LP_ROWB + 64) = rs[S];
     };
-
-    gload(0);
-    lstore(lds);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    // one k-step: MFMAs on LDS stage kt & 1, then k-step kt + 1 (register set (kt + 1) % DEPTH, in flight since step kt + 1 - DEPTH)
+    // is quantised into the other stage and its set is refilled with k-step kt + 1 + DEPTH
+    auto body = [&](auto nxt_tag, int kt) {
         const char* cur = lds + (kt & 1) * STAGE;
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
         // Operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 with 8-bit elements (found by probing; tools/debug_fp8.py): lane
         // (i = lane & 31, h = lane >> 5) holds row i, k = 16 h + [0, 16) in VGPR 0-3 and k = 32 + 16 h + [0, 16) in VGPR 4-7; the
         // E8M0 scale of the row's k-block b (k in [32 b, 32 b + 32)) is taken from the lane with h = b.
@@ -254,9 +315,16 @@ __global__ __launch_bounds__(256, 2) void gemm_lp_kernel(const lvae_gemm_desc d,
             acc[0][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bfr, acc[0][b], 0, 0, 0, sa[0], 0, sb);
             acc[1][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[1], bfr, acc[1][b], 0, 0, 0, sa[1], 0, sb);
         }
-        if (more) lstore(lds + ((kt & 1) ^ 1) * STAGE);
+        lstore(nxt_tag, lds + ((kt & 1) ^ 1) * STAGE);
+        gload(nxt_tag, kt + 1 + DEPTH);
         __syncthreads();
-    }
+    };
+    using T0 = std::integral_constant<int, 0>;
+    gload(T0{}, 0);
+    lstore(T0{}, lds);
+    gload(T0{}, 1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) body(T0{}, kt);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     const int rr = d.r, r2 = rr * rr, epi = d.epi, store = d.store;
@@ -301,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lp_kernel(const lvae_gemm_desc d,
                 for (int b = 0; b < TN; ++b) {
                     float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
                     float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
-                    if (epi == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+                    if (epi == LVAE_EPI_BIAS_GELU) { v0 = lp_gelu(v0); v1 = lp_gelu(v1); v2 = lp_gelu(v2); v3 = lp_gelu(v3); }
                     else if (epi == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
                     quad_transpose(v0, v1, v2, v3, lj);
                     if (rok && cok4[b]) {
@@ -348,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lp_kernel(const lvae_gemm_desc d,
                     else obase = ((long)bb * cp * (d.H * rr) + (long)h * rr) * (d.W * rr) + (long)w * rr;
                 }
                 float v = acc[a][b][r] + bv;
-                if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
+                if (epi == LVAE_EPI_BIAS_GELU) v = lp_gelu(v);
                 else if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
                     const long ro = (long)row * d.ldres + col;
                     const float rv = OBF ? __uint_as_float((unsigned)((const unsigned short*)d.res)[ro] << 16) : d.res[ro];
@@ -374,9 +442,12 @@ template <int AMODE, bool ABF, bool OBF>
 int launch_lp_tn(const lvae_gemm_desc* d, hipStream_t st) {
     // 128 x 128 tiles (TN = 2) unless N <= 64; the 128 x 192 instance needs more than 256 registers per lane with the quantiser's
     // temporaries (hipcc spills ~400 of them to scratch: measured 3x slower) and is not built.  Results do not depend on the choice.
-    const int tn = d->N <= 64 ? 1 : 2;
+    // fp32 A (the K = z operands of z_proj): 64-wide tiles (its wider instances would spill); N a multiple of 192: 128 x 192 tiles
+    // (N = 192 is ONE column tile: A is read once instead of twice, and no half-empty 128 x 128 tile)
+    const int tn = (d->N <= 64 || !ABF) ? 1 : ((d->N % 192 == 0) ? 3 : 2);
     if (tn == 1) return launch_lp<1, AMODE, ABF, OBF>(d, st);
-    return launch_lp<2, AMODE, ABF, OBF>(d, st);
+    if constexpr (ABF) return tn == 3 ? launch_lp<3, AMODE, ABF, OBF>(d, st) : launch_lp<2, AMODE, ABF, OBF>(d, st);
+    return -22;
 }
 
 template <bool ABF, bool OBF>
@@ -393,7 +464,7 @@ int launch_lp_mode(const lvae_gemm_desc* d, hipStream_t st) {
 
 // prec 3 entry (called by lvae_gemm_f32 after the common argument checks)
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st) {
-    if (!d->Wt16 || (d->ldw & 63) || d->ldw < d->K || (d->K & 7) || (d->K0 & 7) || d->ksplit > 1) return -22;
+    if (!d->Wt16 || (d->ldw & 63) || d->ldw < d->K || (d->K & 7) || (d->K0 & 7) || d->ksplit > 1 || d->a_gelu) return -22;
     const int esz = d->a_bf16 ? 2 : 4;
     if (d->a_mode == LVAE_A_PLAIN) {
         if ((d->lda0 * esz) & 15 || d->K0 + d->K1 != d->K || (d->K1 && (!d->A1 || ((d->lda1 * esz) & 15) || (d->K1 & 7)))) return -22;

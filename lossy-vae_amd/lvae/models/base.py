@@ -48,7 +48,7 @@ def pack_mxfp8(t):
     bits = amax.view(torch.int32)
     eb = ((bits >> 23) & 0xff) - 8
     eb = eb + ((bits & 0x7fffff) > 0x600000).to(torch.int32)
-    eb = eb.clamp(0, 254)
+    eb = eb.clamp(1, 254)
     inv = ((254 - eb) << 23).view(torch.float32)                      # 2^(127 - eb), exact
     q = (blk * inv.unsqueeze(2)).to(torch.float8_e4m3fn).view(torch.uint8).reshape(n, kp)
     return torch.cat([q.reshape(-1), eb.to(torch.uint8).reshape(-1)]).contiguous()
