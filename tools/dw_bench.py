@@ -6,7 +6,7 @@ import torch
 from lvae import _native
 L = _native.lib()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-shapes = [(8, 128, 192, 192, 7), (8, 128, 192, 128, 7), (8, 64, 96, 384, 7), (8, 64, 96, 256, 7), (8, 32, 48, 384, 5), (8, 32, 48, 512, 5),
+shapes = [(8, 128, 192, 192, 1), (8, 128, 192, 192, 3), (8, 128, 192, 192, 5), (8, 128, 192, 192, 7), (8, 128, 192, 128, 7), (8, 64, 96, 384, 7), (8, 64, 96, 256, 7), (8, 32, 48, 384, 5), (8, 32, 48, 512, 5),
           (8, 16, 24, 512, 3), (1, 128, 192, 192, 7), (1, 64, 96, 384, 7)]
 only = os.environ.get('DW_ONLY')
 if only:
