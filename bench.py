@@ -76,7 +76,9 @@ class KernelTimer:
             import ctypes
             s = torch.cuda.current_stream(plan.device)
             sp = ctypes.c_void_p(s.cuda_stream)
-            for i, (fn, args, label) in enumerate(ops[lo:hi]):
+            for i, (fn, args, label, _side) in enumerate(ops[lo:hi]):
+                if not callable(fn):                     # stream-ordering entry of a two-stream plan: everything runs on ONE stream here
+                    continue
                 sel = pred(fn, args, label)
                 if sel:
                     e0 = torch.cuda.Event(enable_timing=True); e0.record(s)
@@ -268,7 +270,7 @@ def main():
 
     def gemm_descs(plans, pred):
         for key, pl in plans:
-            for fn, a, label in pl.ops:
+            for fn, a, label, _side in pl.ops:
                 if pred(fn, a, label):
                     yield ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
 

@@ -235,6 +235,12 @@ int lvae_sqerr_sum_f32(const float* a, const float* b, double* out, int B, long 
  * identical, which the sharded evaluation needs to reproduce the single-process means bit for bit. */
 int lvae_sqerr_partials_f32(const float* a, const float* b, double* partials, int n_partials, long n, void* stream);
 
+/* Stream ordering for launch plans with independent branches (lvae/engine.py: Plan.fork / Plan.join): an event without timing, and
+ * "work enqueued on to_stream from now on runs after the work enqueued on from_stream so far" (hipEventRecord + hipStreamWaitEvent). */
+void* lvae_event_create(void);
+int   lvae_event_destroy(void* event);
+int   lvae_stream_order(void* from_stream, void* to_stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif

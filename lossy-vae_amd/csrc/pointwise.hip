@@ -1387,5 +1387,20 @@ extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_abi_version(void) { return 12; }
+// ---- stream ordering helpers for launch plans that run independent branches on a side stream (lvae/engine.py: fork / join)
+extern "C" void* lvae_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+extern "C" int lvae_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : -22; }
+// everything enqueued on `to_stream` after this call runs after everything enqueued on `from_stream` before it
+extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
+    if (!ev) return -22;
+    hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)from_stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
+}
+
+extern "C" int lvae_abi_version(void) { return 13; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

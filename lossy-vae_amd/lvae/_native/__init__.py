@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 
@@ -62,6 +62,9 @@ SIGNATURES = {
     'lvae_prior_sample_f32': (_i, [_vp, _vp, C.c_long, _i, _i, C.c_float, C.c_ulonglong, C.c_ulonglong, _vp]),
     'lvae_gaussian_nll_f32': (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),
+    'lvae_event_create': (_vp, []),
+    'lvae_event_destroy': (_i, [_vp]),
+    'lvae_stream_order': (_i, [_vp, _vp, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'lvae_sqerr_partials_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
 }

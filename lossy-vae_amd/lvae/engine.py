@@ -85,6 +85,20 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
     return best
 
 
+_ORDER = object()        # marker of a stream-ordering entry in Plan.ops
+
+
+class _EventHolder:
+    def __init__(self, lib, ev):
+        self.lib, self.ev = lib, ev
+
+    def __del__(self):
+        try:
+            self.lib.lvae_event_destroy(self.ev)
+        except Exception:
+            pass
+
+
 class Plan:
     autotune = os.environ.get('LVAE_AUTOTUNE', '0') == '1'    # opt-in: in-situ gains were within noise
 
@@ -103,6 +117,11 @@ class Plan:
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
+        # Independent branches on a side stream (small maps only: there the GPU is far from full and the launches of a branch are
+        # pure latency): ops recorded between side_begin() / side_end() go to `side_stream`, ordered against the main stream by
+        # fork (side waits for main) / join (main waits for side) events.  Results do not change -- same kernels, same inputs.
+        self.side_stream = None
+        self.on_side = False
 
     # ---- memory
     def buf(self, name, numel, dtype=torch.float32):
@@ -141,7 +160,39 @@ class Plan:
 
     # ---- recording
     def add(self, fn, args, label=''):
-        self.ops.append((fn, tuple(args), label))
+        self.ops.append((fn, tuple(args), label, self.on_side))
+
+    def enable_side_stream(self):
+        if self.side_stream is None and not self.use_graphs:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        return self.side_stream is not None
+
+    def _order(self, side_waits_for_main, label):
+        ev = self.lib.lvae_event_create()
+        if not ev:
+            raise RuntimeError('hipEventCreate failed')
+        self.keep.append(_EventHolder(self.lib, ev))
+        self.ops.append((_ORDER, (bool(side_waits_for_main), ev), label, False))
+
+    def fork(self, label='fork'):
+        """Side-stream work recorded after this point starts after the main-stream work recorded before it."""
+        if self.side_stream is not None:
+            self._order(True, label)
+
+    def join(self, label='join'):
+        """Main-stream work recorded after this point starts after the side-stream work recorded before it."""
+        if self.side_stream is not None:
+            self._order(False, label)
+
+    def side_begin(self):
+        self.on_side = self.side_stream is not None
+
+    def side_end(self):
+        self.on_side = False
+
+    def sname(self, name):
+        """Scratch buffers of side-stream ops are separate from the main stream's (they run concurrently)."""
+        return name + '_side' if self.on_side else name
 
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
@@ -175,18 +226,19 @@ class Plan:
         if ksplit is None:
             ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
         if ksplit > 1:
-            d.ksplit, d.ws = ksplit, self.buf('splitk_ws', ksplit * M * N).data_ptr()
+            d.ksplit, d.ws = ksplit, self.buf(self.sname('splitk_ws'), ksplit * M * N).data_ptr()
             # In-kernel slice reduction (lvae_gemm_desc.cnt: a tile's last-arriving slice workgroup sums the S slabs in place of the
             # second launch) is taken only when the slabs of one tile are small: the last arriver reads S x tile bytes ALONE at the
             # cross-XCD rate (~65 GB/s per workgroup), so with the 128 x 128..192 tiles of the MLP layers (64-98 KB x S) it costs more
             # than the reduce launch it removes (measured on MI355X: 105 -> 100 Mpixels/s at B = 8, 12.1 -> 13.3 ms at B = 1).
             if ksplit * 128 * min(N, 192) * 4 <= INKERNEL_REDUCE_MAX_BYTES:
                 n_cnt = ((M + 63) // 64) * ((N + 31) // 32)
-                cnt = self.bufs.get('splitk_cnt')
+                cname = self.sname('splitk_cnt')
+                cnt = self.bufs.get(cname)
                 if cnt is None or cnt.numel() < n_cnt:
                     if cnt is not None:
                         self.keep.append(cnt)
-                    cnt = self.bufs['splitk_cnt'] = torch.zeros(max(4096, n_cnt), dtype=torch.int32, device=self.device)
+                    cnt = self.bufs[cname] = torch.zeros(max(4096, n_cnt), dtype=torch.int32, device=self.device)
                 d.cnt = cnt.data_ptr()
         if self.autotune and M * N >= 64 * 64:
             sp = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -202,8 +254,12 @@ class Plan:
 
     def _run_eager(self, lo, hi, s):
         sp = ctypes.c_void_p(s)
-        for fn, args, label in self.ops[lo:hi]:
-            rc = fn(*args, sp)
+        ss = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else None
+        for fn, args, label, side in self.ops[lo:hi]:
+            if fn is _ORDER:
+                rc = self.lib.lvae_stream_order(sp, ss, args[1]) if args[0] else self.lib.lvae_stream_order(ss, sp, args[1])
+            else:
+                rc = fn(*args, ss if side else sp)
             if rc != 0:
                 raise RuntimeError(f'native launch "{label}" failed: rc={rc}')
 

@@ -23,6 +23,22 @@ import torch.nn as nn
 from .. import _native
 
 
+def log_spaced_table(lo, hi, steps):
+    """exp(linspace(log lo, log hi, steps)) as float32 -- the scale tables of the reference (entropy_coding.py:72-75: 64 scales
+    0.11..20; qresvae/model.py:317-325: 0.1..20; :60-67: 128 scales) -- evaluated so that every host gives the SAME bits: the
+    reference's `torch.exp(torch.linspace(...))` runs through vectorised float kernels whose last ulp depends on the CPU (AVX2 vs
+    AVX-512 builds of the same torch differ in a few entries), and a table that differs by one ulp moves CDF rows by a count, i.e.
+    makes a stream undecodable on another machine.  Here: the fp32 linspace torch computes (start + step*i for the first half,
+    end - step*(n-1-i) for the second, ONE rounding per element) emulated in float64, then exp in float64 rounded once to float32.
+    Bit-identical to the tables of the reference run that produced tests/golden/*tables.npz (all three tables)."""
+    start, end = np.float32(math.log(lo)), np.float32(math.log(hi))
+    step = np.float32((end - start) / np.float32(steps - 1))
+    s64, e64, d64 = float(start), float(end), float(step)
+    t = np.array([np.float32(s64 + d64 * i) if i < steps // 2 else np.float32(e64 - d64 * (steps - 1 - i)) for i in range(steps)],
+                 dtype=np.float32)
+    return torch.from_numpy(np.exp(t.astype(np.float64)).astype(np.float32))
+
+
 class _Bound(nn.Module):
     """State-dict-compatible stand-in for compressai.ops.LowerBound (one buffer `bound`, shape (1,))."""
     def __init__(self, bound):
@@ -53,7 +69,7 @@ class DiscretizedGaussian(nn.Module):
 
     @staticmethod
     def _get_default_scale_table():
-        return torch.exp(torch.linspace(math.log(0.11), math.log(20.0), steps=64))
+        return log_spaced_table(0.11, 20.0, 64)
 
     def _standardized_cumulative(self, inputs):
         if self.cdf_form == 'erf':      # torch.distributions.Normal(0,1).cdf, entropy_coding.py:70,81-82

@@ -28,6 +28,9 @@ from ..base import CodecBase, on_model_device
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 
 EMBED_DIM = 256
+# encode plans up to this many pixels per launch run posterior0 and the prior heads on a side stream (single images / small batches:
+# the GPU is far from full and every launch of a branch is latency on the critical path); larger batches fill the chip anyway
+SIDE_STREAM_MAX_PIXELS = 2 * 512 * 768
 
 
 # ----------------------------------------------------------------------------------------------- parameter holders
@@ -216,8 +219,8 @@ class _NetPlan(Plan):
         self.lat_shapes = []                    # (z, HW)
 
     def scratch(self, M, C, hid):
-        y = self.buf('y', M * C, self.adt)
-        h = self.buf('hid', M * hid, self.adt)
+        y = self.buf(self.sname('y'), M * C, self.adt)
+        h = self.buf(self.sname('hid'), M * hid, self.adt)
         return y, h
 
     def cnx(self, p, m, x, out, H, W):
@@ -241,11 +244,14 @@ class _NetPlan(Plan):
         self.gemm(A0=x, K0=m.cin, M=M, N=m.cout * m.rate ** 2, Wt=pk.p(p + '.w'), bias=pk.p(p + '.b'), out=out,
                   store=_native.ST_IMAGE if final else _native.ST_SHUFFLE, r=m.rate, H=H, W=W, label=p + '.up')
 
-    def prior(self, p, m, f, H, W):
+    def prior(self, p, m, f, H, W, side_head=False):
         """transform_prior (qarv/model.py:44-54) + build_indexes (:106/:112). Returns pm buffer."""
         pk, lib, B = self.pk, self.lib, self.B
         M, z = B * H * W, m.zdim
         self.cnx(p + '.resnet_front', m.resnet_front, f, f, H, W)
+        if side_head:          # encoder: the prior head is off the critical path until quantize -- it runs beside posterior1 / post_merge
+            self.fork(p + '.fork_prior')
+            self.side_begin()
         prm = self.buf('prm', M * 2 * z)
         self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
                   out=prm.data_ptr(), out_bf16=0, label=p + '.prior')
@@ -257,6 +263,7 @@ class _NetPlan(Plan):
         self.idx_off.append(ioff)
         self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
                                             pk.scale_table.numel(), pk.scale_bound, B, H * W, z), p + '.prior_index')
+        self.side_end()
         return pm, ioff
 
     def fuse_and_end(self, p, m, f, zhat, H, W):
@@ -293,6 +300,8 @@ class _EncPlan(_NetPlan):
         super().__init__(model, pk, B)
         lib = self.lib
         self.im = self.new(B * 3 * H * W)
+        if B * H * W <= SIDE_STREAM_MAX_PIXELS:
+            self.enable_side_stream()
         self.alloc_latent_io(H // 64, W // 64)
         self.nats = self.new(model.num_latents * B, torch.float64) if with_bits else None   # [block][image] sum(-ln P)
         feats = {}
@@ -333,14 +342,20 @@ class _EncPlan(_NetPlan):
             p = f'dec_blocks.{i}'
             if m.kind == 'vrlv':
                 M, z = B * h * w, m.zdim
-                pm, ioff = self.prior(p, m, f.data_ptr(), h, w)
                 ef, eh, ew = feats[m.enc_key]
                 assert (eh, ew) == (h, w)
                 e = self.buf('post_e', M * m.enc_width, self.adt)
                 g = self.buf('post_g', M * m.width, self.adt)
                 mg = self.buf('post_m', M * m.width, self.adt)
+                # posterior0 works on the ENCODER feature only (qarv/model.py:56-70): with a side stream it runs beside resnet_front
+                # (and the prior head beside posterior1) instead of in line with them; both are joined before post_merge
+                self.fork(p + '.fork_post0')
+                self.side_begin()
                 self.cnx(p + '.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), h, w)
+                self.side_end()
+                pm, ioff = self.prior(p, m, f.data_ptr(), h, w, side_head=True)
                 self.cnx(p + '.posterior1', m.posterior1, f.data_ptr(), g.data_ptr(), h, w)
+                self.join(p + '.join')
                 self.gemm(A0=g.data_ptr(), K0=m.width, A1=e.data_ptr(), K1=m.enc_width, lda1=m.enc_width, M=M, N=m.width,
                           Wt=pk.p(p + '.post_merge.w'), bias=pk.p(p + '.post_merge.b'), out=mg.data_ptr(),
                           label=p + '.post_merge')

@@ -23,7 +23,7 @@ from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
 from ..base import CodecBase, on_model_device
-from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
+from ..entropy_coding import DiscretizedGaussian, log_spaced_table, rans_decode_streams, rans_encode_streams
 from ..qarv.model import UpParams, _conv
 
 
@@ -134,7 +134,7 @@ class GaussianNLLOutParams(nn.Module):
         self.discrete_gaussian.register_buffer('scale_bound', torch.Tensor([0.11]))
 
     def update(self):
-        table = torch.exp(torch.linspace(math.log(0.11), math.log(20), steps=128))
+        table = log_spaced_table(0.11, 20, 128)
         self.discrete_gaussian.update_scale_table(table, force=True)
 
 
@@ -493,7 +493,7 @@ class HierarchicalVAE(CodecBase):
     def compress_mode(self, mode=True):
         """(:640-647) -> QLatentBlockX.update (:317-325): 64 log-spaced scales 0.1..20, stock erfc-form tables."""
         if mode:
-            table = torch.exp(torch.linspace(math.log(0.1), math.log(20), steps=64))
+            table = log_spaced_table(0.1, 20, 64)
             first = None
             for b in self.decoder.dec_blocks:
                 if b.kind != 'qlb':

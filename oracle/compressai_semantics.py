@@ -67,6 +67,20 @@ def pmf_to_quantized_cdf(pmf, precision=16):
     return out.astype(np.int64).tolist()
 
 
+def log_spaced_table(lo, hi, steps):
+    """The reference's `torch.exp(torch.linspace(log lo, log hi, steps))` scale tables (entropy_coding.py:72-75,
+    qresvae/model.py:60-67,317-325) with every rounding pinned (fp32 linspace with one rounding per element emulated in float64,
+    float64 exp rounded once): the vectorised torch kernels differ in the last ulp between CPUs, and the oracle must build the same
+    tables on the GPU box's host as here.  Bit-identical to the reference run behind tests/golden/*tables.npz."""
+    import math
+    start, end = np.float32(math.log(lo)), np.float32(math.log(hi))
+    step = np.float32((end - start) / np.float32(steps - 1))
+    s64, e64, d64 = float(start), float(end), float(step)
+    t = np.array([np.float32(s64 + d64 * i) if i < steps // 2 else np.float32(e64 - d64 * (steps - 1 - i)) for i in range(steps)],
+                 dtype=np.float32)
+    return torch.from_numpy(np.exp(t.astype(np.float64)).astype(np.float32))
+
+
 def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 

@@ -98,7 +98,7 @@ class DiscretizedGaussianOracle(cs.GaussianConditional):
     erf-form fp32 CDF = td.Normal(0,1).cdf (:70,81-82), scipy ppf quantile (:77-79)."""
     def __init__(self):
         cs.EntropyModel.__init__(self)
-        scale_table = torch.exp(torch.linspace(math.log(0.11), math.log(20.0), steps=64))
+        scale_table = cs.log_spaced_table(0.11, 20.0, 64)        # entropy_coding.py:72-75, host-independent bits
         self.register_buffer('scale_table', scale_table, persistent=False)
         self.tail_mass = float(1e-9)
         self.lower_bound_scale = cs.LowerBound(scale_table[0])

@@ -152,13 +152,13 @@ class QresOracle:
 
     def compress_mode(self, mode=True):
         if mode:                                                                           # model.py:317-325
-            scale_table = torch.exp(torch.linspace(math.log(0.1), math.log(20), steps=64))
+            scale_table = cs.log_spaced_table(0.1, 20, 64)
             self.dg.update_scale_table(scale_table)
             self.dg.update()
             if 'out_net' in self.arch:                                                     # GaussianNLLOutputNet.update (:59-67)
                 self.out_dg = cs.GaussianConditional(None, scale_bound=0.11)
                 lower = self.out_dg.lower_bound_scale.bound.item()
-                self.out_dg.update_scale_table(torch.exp(torch.linspace(math.log(lower), math.log(20), steps=128)))
+                self.out_dg.update_scale_table(cs.log_spaced_table(lower, 20, 128))
                 self.out_dg.update()
 
     def encoder(self, x):                                                                  # model.py:200-207

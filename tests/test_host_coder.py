@@ -174,3 +174,14 @@ def test_update_is_device_independent(golden_dir, monkeypatch):
     dg2 = DiscretizedGaussian(cdf_form='erf')
     dg2.update()
     assert dg2._quantized_cdf.shape == (64, 249)
+
+
+def test_scale_tables_are_host_independent_and_equal_the_reference(golden_dir):
+    """log_spaced_table pins every rounding of the reference's torch.exp(torch.linspace(...)) scale tables (vectorised torch kernels
+    differ in the last ulp between CPUs -- seen between the build container and the MI355X box's host): all three tables the codecs
+    use equal the reference run's bit for bit, product and oracle alike."""
+    from lvae.models.entropy_coding import log_spaced_table
+    for fn in (log_spaced_table, cs.log_spaced_table):
+        assert np.array_equal(fn(0.11, 20.0, 64).numpy(), np.load(os.path.join(golden_dir, 'discretized_gaussian_tables.npz'))['scale_table'])
+        assert np.array_equal(fn(0.1, 20, 64).numpy(), np.load(os.path.join(golden_dir, 'gaussian_conditional_tables.npz'))['scale_table'])
+        assert np.array_equal(fn(0.11, 20, 128).numpy(), np.load(os.path.join(golden_dir, 'qres34m_lossless_64x128.npz'))['scale_table'])
