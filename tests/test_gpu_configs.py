@@ -236,3 +236,20 @@ def test_rate_targeting_script(offline_home, tmp_path):
     for (s0, l0), l1 in zip(zip(sizes, lmbs), lmbs[1:]):
         assert (l1 < l0) == (s0 > 60000)
     assert os.path.getsize(tmp_path / 'x.bits') == sizes[-1]
+
+
+def test_eval_theoretical_robust_decoding_and_lossless_scripts(offline_home, tmp_path):
+    """The remaining CLIs of SURVEY.md 8(f): scripts/qarv/eval-theoretical.py (reference :8-31, `pretrained=True` default),
+    scripts/qarv/robust-decoding.py in all four modes (reference :38-56) and scripts/qresvae/evaluate-lossless.py."""
+    out = _run([os.path.join(REPO, 'scripts', 'qarv', 'eval-theoretical.py'), '-n', 'clic2022-test', '-s', '2', '-l', '64', '512'],
+               offline_home, tmp_path)
+    assert '================ clic2022-test ================' in out
+    rows = {l.split('=')[0].strip(): l for l in out.splitlines() if '= [' in l}
+    assert {'loss', 'bpp', 'psnr', 'lambda'} <= set(rows) and rows['bpp'].count(',') == 1
+    for mode in ('progressive', 'exclude', 'reverse', 'single'):
+        out = _run([os.path.join(REPO, 'scripts', 'qarv', 'robust-decoding.py'), '--synthetic', '128', '192', '--mode', mode,
+                    '--out', str(tmp_path / f'{mode}.png')], offline_home, tmp_path)
+        assert out.count(f'{mode}=') == 9, out                       # one line per latent block (anchor)
+        assert os.path.getsize(tmp_path / f'{mode}.png') > 0
+    out = _run([os.path.join(REPO, 'scripts', 'qresvae', 'evaluate-lossless.py'), '--synthetic', '3'], offline_home, tmp_path)
+    assert 'Average bpp:' in out and float(out.split('Average bpp:')[1].split()[0]) > 0, out      # asserts bit-exact round trips inside
