@@ -185,32 +185,46 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
     uint64_t x = (uint64_t)ptr[0] | ((uint64_t)ptr[1] << 32);
     ptr += 2;
     bool overrun = false;
-    // Per-row 256-bucket start table, built lazily for the rows this stream touches: lut[row][cf >> 8] = largest s
-    // with cdf[s] <= (bucket << 8).  The symbol is then found by a short forward scan (replaces upstream's linear
-    // find_if over up to 249 entries and a branchy binary search; 16 KB, L1-resident).
-    uint8_t lut[256][256];
+    // Per-row decode tables, built lazily for the rows this stream touches (1.25 KB per row):
+    //   lut[row][b] = largest s with cdf[s] <= (b << 8)                       (256 buckets of 256 counts)
+    //   ent[row][b] = cdf[s] | freq(s) << 16  if the whole bucket lies inside symbol s ("pure"), else 0
+    // The serial dependency of a rANS stream is  state -> cf -> symbol -> (start, freq) -> state.  Upstream's linear find_if, and
+    // the first form here (bucket -> forward scan of data-dependent length -> two cdf loads), put dependent loads and a poorly
+    // predictable branch into that chain for every symbol.  Most of a stream's probability mass sits in symbols much wider than a
+    // bucket, so for most symbols ONE load (ent) now yields start and freq and the symbol id comes off the critical path; only
+    // buckets that contain a boundary take the scan.  Measured: tools/rans_bench.py.
+    struct RowTab { uint32_t ent[256]; uint8_t lut[256]; };
+    RowTab tabs[256];
     bool have[256] = {false};
     for (size_t i = 0; i < n; ++i) {
         const int32_t row_i = idx[i];
         const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
         const int32_t size = cdf_len[row_i];
         const int32_t max_value = size - 2;
+        RowTab& T = tabs[row_i];
         if (!have[row_i]) {
             if (size < 2 || size > 257) return -4;
             int32_t sidx = 0;
             for (int b = 0; b < 256; ++b) {
                 const uint32_t v = (uint32_t)b << 8;
                 while (sidx + 1 < size - 1 && (uint32_t)cdf[sidx + 1] <= v) ++sidx;
-                lut[row_i][b] = (uint8_t)sidx;
+                T.lut[b] = (uint8_t)sidx;
+                const bool pure = (uint32_t)cdf[sidx + 1] >= v + 256;       // the next boundary is beyond the bucket
+                T.ent[b] = pure ? ((uint32_t)cdf[sidx] | ((uint32_t)(cdf[sidx + 1] - cdf[sidx]) << 16)) : 0u;
             }
             have[row_i] = true;
         }
         const uint32_t cf = (uint32_t)(x & 0xFFFF);
-        int32_t lo = lut[row_i][cf >> 8];
-        while ((uint32_t)cdf[lo + 1] <= cf) ++lo;       // cdf[size-1] = 65536 > cf terminates the scan
-        const int32_t s = lo;
-        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
-        x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFF) - start;
+        const uint32_t e = T.ent[cf >> 8];
+        int32_t s = T.lut[cf >> 8];
+        uint32_t start, freq;
+        if (__builtin_expect(e != 0, 1)) {
+            start = e & 0xFFFFu; freq = e >> 16;
+        } else {
+            while ((uint32_t)cdf[s + 1] <= cf) ++s;      // cdf[size-1] = 65536 > cf terminates the scan
+            start = (uint32_t)cdf[s]; freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+        }
+        x = (uint64_t)freq * (x >> kPrecision) + cf - start;
         if (x < kRansL) {
             uint32_t wv = 0;
             if (ptr < end) wv = *ptr; else overrun = true;
