@@ -19,6 +19,7 @@
 //    residual rows have the output's type.
 #include "gemm_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -182,7 +183,7 @@ __device__ __forceinline__ f32x4 lp_load4(const float* base, long off) {
 }
 
 template <int TN, int AMODE, bool ABF, bool OBF>
-__global__ __launch_bounds__(256, 2) void gemm_lp_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
+__global__ __launch_bounds__(256, (TN <= 2 && ABF ? 3 : 2)) void gemm_lp_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     constexpr int BM = 128, BN = 64 * TN, STAGE = (BM + BN) * LP_ROWB;
     constexpr int NWCH = BN * 4, NW = (NWCH + 255) / 256;          // 16-B W chunks per stage / per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -444,7 +445,12 @@ int launch_lp_tn(const lvae_gemm_desc* d, hipStream_t st) {
     // temporaries (hipcc spills ~400 of them to scratch: measured 3x slower) and is not built.  Results do not depend on the choice.
     // fp32 A (the K = z operands of z_proj): 64-wide tiles (its wider instances would spill); N a multiple of 192: 128 x 192 tiles
     // (N = 192 is ONE column tile: A is read once instead of twice, and no half-empty 128 x 128 tile)
-    const int tn = (d->N <= 64 || !ABF) ? 1 : ((d->N % 192 == 0) ? 3 : 2);
+    int tn = (d->N <= 64 || !ABF) ? 1 : ((d->N % 192 == 0) ? 3 : 2);
+    {
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("LVAE_LP_TN"); force = e ? atoi(e) : 0; }
+        if (force >= 1 && force <= 3 && ABF && d->N > 64) tn = force;
+    }
     if (tn == 1) return launch_lp<1, AMODE, ABF, OBF>(d, st);
     if constexpr (ABF) return tn == 3 ? launch_lp<3, AMODE, ABF, OBF>(d, st) : launch_lp<2, AMODE, ABF, OBF>(d, st);
     return -22;
