@@ -1,0 +1,361 @@
+// dwconv_cl.hip -- depthwise k x k conv + bias -> LayerNorm(C) -> per-channel affine (LN weight/bias or AdaLN scale/shift) over an
+// NHWC map, "channel-per-lane" form (lvae/models/common.py:145-152; qresvae/model.py:168-176).
+//
+// The earlier forms of this operator (pointwise.hip) give every pixel to a few lanes that hold ALL its channels, because the
+// LayerNorm wants them together; the k*k weights of so many channels do not fit in registers, so their tap loop is fed from LDS and
+// is bound by LDS fragment reads (17 ds_read_b128 per 56 packed FMAs: DESIGN.md 5b).  Here the roles are swapped:
+//   * a lane owns ONE CHANNEL of an 8-pixel-wide column strip and keeps its k*k weights in registers (49 VGPRs at k = 7); a wave is
+//     64 channels of one strip, a workgroup the C/64 waves of that strip.  Two horizontally adjacent output pixels share one
+//     v_pk_fma_f32 (the weight is broadcast to both halves with op_sel); the pixel pairs that start at an odd column are
+//     assembled with two moves -- 64-bit operands must be even-aligned;
+//   * a workgroup produces a tile of 8 x TH output pixels: the TH + k - 1 input rows are visited ONCE, top to bottom (8 + k - 1
+//     pixels per lane and row), and each feeds the up to k output rows it
+//     belongs to; TH x 8 accumulators per lane.  The whole tile is straight-line code (every register index static, no phi copies).
+//     No LDS reads in the tap loop, no weight traffic.  Rows reach the registers through wave-private LDS row buffers filled by DMA
+//     two rows ahead (see dma_row / read_row).  Taps are visited column-major inside a row, which leaves every output's
+//     accumulation order -- bias, then taps (i, j) ascending -- unchanged;
+//   * a finished output row is transposed through a wave-private LDS tile into a pixel-major layout (8 lanes per pixel, 8 channels
+//     per lane: 16-B accesses, 128 B contiguous per pixel and store), where the two-pass LayerNorm statistics cost 7 adds + 3 DPP
+//     steps per lane; the C/64 waves exchange their per-pixel partial sums through LDS (two workgroup barriers per output row).
+// Zero padding comes from the buffer unit: a row's resource descriptor covers exactly that image row (num_records = 0 for rows outside
+// the image), so columns left / right of the image and rows above / below read as hardware zeros without masks on the data path.
+// TH (8, 4, 2 or 1 output rows per workgroup; k - 1 halo rows are re-read per tile, from L2) only changes the parallelism, never an
+// output bit, so the launcher picks it from the map size.
+//
+// Arithmetic: the conv chain is the earlier kernels' (same bits); the LayerNorm uses THIS kernel's association (8 channels in a
+// lane: ((a0+a1)+(a2+a3)) + ((b0+b1)+(b2+b3)), 8 lanes by xor 1, xor 2, half-mirror, then the waves in ascending order) and
+// rstd = v_rsq_f32 refined by one Newton step (the earlier forms: 1 / sqrtf), so the operator is dispatched to this kernel by (C, k)
+// alone -- never by batch or map size: batch-of-8 == 8 single images, and the encoder and the decoder see the same bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/lvae_hip.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sum8(float s) {          // total over the 8 lanes of a pixel group, the same bits in all of them
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x141, 0xF, 0xF, true));      // row_half_mirror
+    return s;
+}
+__device__ __forceinline__ unsigned f2bf_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// acc += x * w.lo (or w.hi) in both halves: v_pk_fma_f32 with the weight broadcast by op_sel.  Inline asm because hipcc gives every
+// broadcast scalar a 64-bit register pair of its own (the odd half stays empty): 98 instead of 50 registers for the 7 x 7 weights.
+// The weight pair is src0 in the high-half form ON PURPOSE.  With the pair as src1 (`op_sel:[0,1,0]`: the LOW lane selects the HIGH
+// dword of src1 -- a form hipcc itself never emits for packed f32) the low lane's result was occasionally wrong on MI355X whenever
+// MFMA kernels shared the CUs: 20-30 % of the launches beside split-K GEMMs on a second stream had a few pixels off (always even
+// columns, i.e. low lanes), 0 of 400 alone, 0 of 400 with the pair as src0 (`op_sel:[1,0,0]`), 0 of 400 with a swapped copy and no
+// low-lane selection.  tests/test_gpu_kernels.py::test_dwconv_ln_beside_gemms keeps watching it.
+__device__ __forceinline__ void pk_fma_wlo(f32x2& a, f32x2 x, f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(x), "v"(w));
+}
+__device__ __forceinline__ void pk_fma_whi(f32x2& a, f32x2 x, f32x2 w) {
+    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(x), "v"(w));
+}
+
+// static_for<N>(f): f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The row / pixel loops MUST be unrolled (every
+// accumulator and weight index has to be static); `#pragma unroll` gives up above ~10 rows (the accumulators then land in scratch).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+constexpr int CL_SW = 8;                    // output pixels per lane along W
+constexpr int CL_TILE = 8 * 96;             // floats of a wave's transpose tile: 8 pixels x 384 B (64 channels + pad: conflict-free b128 reads)
+
+// amdgpu_waves_per_eu pins the register budget: three waves per SIMD (168 VGPRs) for the k = 7, TH = 8 tiles, four (128) for the others.
+// Measured at k = 7, C = 192: 85 us at three waves, 106 us when two more registers push the kernel to two.
+template <int KS, bool BF> struct ClGeom {
+    static constexpr int XW = CL_SW + KS - 1;                       // input pixels per lane and row
+    static constexpr int PPI = BF ? 8 : 4;                          // pixels per LDS-DMA instruction (64 lanes x 16 B = 64 channels x PPI pixels)
+    static constexpr int NG = (XW + PPI - 1) / PPI;                 // DMA instructions per row
+    static constexpr int ROWF = NG * 256;                           // floats of one row buffer (NG KiB)
+};
+
+template <int KS, int NW, bool BF> constexpr int cl_lds_bytes() { return (NW * (CL_TILE + 2 * ClGeom<KS, BF>::ROWF) + 128 + 128 * NW) * 4; }
+// waves per SIMD the kernel is compiled for: what the registers allow (above), capped by what 160 KB of LDS lets reside on a CU
+template <int KS, int NW, int TH, bool BF> constexpr int cl_waves() {
+    const int by_regs = (KS == 7 && TH == 8) ? 3 : 4;
+    const int by_lds = ((160 * 1024) / cl_lds_bytes<KS, NW, BF>()) * NW / 4;
+    return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
+}
+
+template <int KS, int NW, int TH, bool BF>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_waves<KS, NW, TH, BF>(), cl_waves<KS, NW, TH, BF>()))) void dwconv_ln_cl_kernel(
+    const void* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ aw,
+    const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy) {
+    using G = ClGeom<KS, BF>;
+    constexpr int C = 64 * NW, P = (KS - 1) / 2, SW = CL_SW, XW = G::XW, ES = BF ? 2 : 4, KK = KS * KS, NR = TH + KS - 1;
+    constexpr int NG = G::NG, ROWF = G::ROWF, PPI = G::PPI;
+    static_assert(XW % 2 == 0, "pixel pairs");
+    // per wave: the LayerNorm transpose tile and two row buffers; then the partial sums [stat][pixel][wave (8)] and the affine parameters
+    constexpr int WAVEF = CL_TILE + 2 * ROWF;
+    __shared__ __attribute__((aligned(16))) float lds[NW * WAVEF + 2 * 8 * 8 + 2 * C];
+    static_assert(sizeof(float) * (NW * WAVEF + 2 * 8 * 8 + 2 * C) == cl_lds_bytes<KS, NW, BF>(), "LDS size formula");
+    float* const red = lds + NW * WAVEF;
+    float* const prm = red + 2 * 8 * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p8 = lane >> 3, blk = lane & 7;          // LayerNorm layout: pixel of the strip, 4-channel block (and block + 8)
+    long wg;
+    {
+        const long nb = gridDim.x, b = blockIdx.x, q = nb / 8, r = nb % 8, xcd = b % 8, loc = b / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;      // XCD-aware: neighbours in (sy, sx) share an L2
+    }
+    const int sx = (int)(wg % n_sx), sy = (int)((wg / n_sx) % n_sy);
+    const long b = wg / ((long)n_sx * n_sy);
+    const int c0 = 64 * wave + lane;                   // conv layout: this lane's channel
+    const int x0 = sx * SW;
+    const int y0 = sy * TH;
+    const int rowbytes = W * C * ES;
+    const char* const xin = (const char*)x + b * (long)H * rowbytes;
+    char* const yout = (char*)y + b * (long)H * rowbytes;
+
+    auto row_rsrc = [&](const char* base, int r) {     // rows outside the image: an empty descriptor (loads give 0, stores are dropped)
+        const bool ok = r >= 0 && r < H;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)(ok ? r : 0) * rowbytes), 0, ok ? rowbytes : 0, 0x00020000);
+    };
+    // Input rows travel global -> LDS by DMA (buffer_load_dwordx4 ... lds: 16 B per lane, PPI pixels x 64 channels per instruction, no
+    // staging registers) and LDS -> registers as one dword per lane and pixel.  Per-lane dword loads straight from global memory are
+    // bound by the texture-address unit (one wave instruction per ~16 cycles whatever its width: 16 B/clk/CU at 4 B per lane -- measured
+    // 85 us of which 35 were the loads); the DMA form needs 4x fewer vector-memory instructions.
+    // A negative offset (left of the image) wraps to a huge unsigned one: out of range like the columns right of the image -> zeros.
+    const int dvoff0 = ((x0 - P + lane / (64 / PPI)) * C + 64 * wave + (lane % (64 / PPI)) * (16 / ES)) * ES;
+    float* const rowbuf = lds + wave * WAVEF + CL_TILE;
+    auto dma_row = [&](int r, int buf) {
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(xin, r);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rowbuf + buf * ROWF + g * 256), 16,
+                                                     dvoff0 + g * PPI * C * ES, 0, 0, 0);
+    };
+    if constexpr (NR > 0) dma_row(y0 - P, 0);
+    if constexpr (NR > 1) dma_row(y0 - P + 1, 1);
+
+    f32x2 wp[(KK + 1) / 2];                            // tap t in wp[t / 2][t % 2]: the FMAs broadcast either half with op_sel
+#pragma unroll
+    for (int t = 0; t < KK; ++t) wp[t / 2][t % 2] = wt[(long)t * C + c0];
+    if (KK % 2) wp[KK / 2][1] = 0.f;
+    const float bias1 = bias[c0];
+    prm[tid] = aw ? aw[tid] : 1.f;                     // blockDim.x == C
+    prm[C + tid] = ab ? ab[tid] : 0.f;
+    const int chA = 64 * wave + 4 * blk, chB = chA + 32;
+
+    f32x2 acc[TH][SW / 2];
+#pragma unroll
+    for (int th = 0; th < TH; ++th)
+#pragma unroll
+        for (int q = 0; q < SW / 2; ++q) acc[th][q] = (f32x2){bias1, bias1};
+
+    // LDS -> registers: the row buffer is read with inline asm (hipcc would guard every LDS load that may alias an LDS-DMA in flight with
+    // s_waitcnt vmcnt(0), i.e. wait for the row AFTER the one being read); the vmcnt waits below are exact.  bf16 maps: d16_hi loads
+    // put the 16 bits into the upper half of a register whose lower half is (and stays) zero -- the fp32 value, no conversion.
+    f32x2 xp[XW / 2];                                  // the input row: pixel m in xp[m / 2][m % 2]
+#pragma unroll
+    for (int m = 0; m < XW / 2; ++m) xp[m] = (f32x2){0.f, 0.f};
+    const unsigned raddr = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)rowbuf + lane * ES;
+    auto read_row = [&](auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        static_for<XW>([&](auto m_tag) {
+            constexpr int m = decltype(m_tag)::value;
+            float v = xp[m / 2][m % 2];
+            if constexpr (BF) asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(v) : "v"(raddr), "n"(buf * ROWF * 4 + m * 64 * ES));
+            else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(raddr), "n"(buf * ROWF * 4 + m * 64 * ES));
+            xp[m / 2][m % 2] = v;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the weights and row 0 have landed (row 1 may still be in flight)
+    if constexpr (NR > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_row(std::integral_constant<int, 0>{});
+    __syncthreads();                                   // prm visible
+    const float inv_c = 1.0f / (float)C;
+    float* const tile = lds + wave * WAVEF;
+
+    // LayerNorm + affine + store of one finished output row (absolute row ya)
+    auto finish_row = [&](const f32x2 (&a)[SW / 2], int ya) {
+#pragma unroll
+        for (int q = 0; q < SW; ++q) tile[q * 96 + lane] = a[q / 2][q % 2];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-private tile: LDS executes a wave's accesses in order
+        f32x4 vA = *(const f32x4*)(tile + p8 * 96 + 4 * blk), vB = *(const f32x4*)(tile + p8 * 96 + 32 + 4 * blk);
+        float s = ((vA[0] + vA[1]) + (vA[2] + vA[3])) + ((vB[0] + vB[1]) + (vB[2] + vB[3]));
+        s = sum8(s);
+        if (blk == 0) red[p8 * 8 + wave] = s;
+        __syncthreads();
+        float tot = red[p8 * 8];
+#pragma unroll
+        for (int v = 1; v < NW; ++v) tot += red[p8 * 8 + v];
+        const float mean = tot * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vA[e] -= mean; sq = fmaf(vA[e], vA[e], sq); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vB[e] -= mean; sq = fmaf(vB[e], vB[e], sq); }
+        sq = sum8(sq);
+        if (blk == 0) red[64 + p8 * 8 + wave] = sq;
+        __syncthreads();
+        float totq = red[64 + p8 * 8];
+#pragma unroll
+        for (int v = 1; v < NW; ++v) totq += red[64 + p8 * 8 + v];
+        // the affine parameters come from LDS: in registers across the tap loop they would cost 16 VGPRs (what separates the k = 7,
+        // TH = 8 instance from three waves per SIMD), and global loads here would share the in-order vmcnt with the row DMA
+        const f32x4 awA = *(const f32x4*)(prm + chA), awB = *(const f32x4*)(prm + chB);
+        const f32x4 abA = *(const f32x4*)(prm + C + chA), abB = *(const f32x4*)(prm + C + chB);
+        const float var = fmaf(totq, inv_c, 1e-6f);                    // >= 1e-6: no special cases for the reciprocal square root
+        float rstd = __builtin_amdgcn_rsqf(var);
+        rstd = rstd * fmaf(-0.5f * var, rstd * rstd, 1.5f);            // one Newton step
+        const int xs = x0 + p8;
+        const __amdgpu_buffer_rsrc_t ro = row_rsrc(yout, ya);
+        f32x4 oA, oB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { oA[e] = fmaf(vA[e] * rstd, awA[e], abA[e]); oB[e] = fmaf(vB[e] * rstd, awB[e], abB[e]); }
+        if (BF) {
+            const u32x2 qa = {f2bf_rne(oA[0]) | (f2bf_rne(oA[1]) << 16), f2bf_rne(oA[2]) | (f2bf_rne(oA[3]) << 16)};
+            const u32x2 qb = {f2bf_rne(oB[0]) | (f2bf_rne(oB[1]) << 16), f2bf_rne(oB[2]) | (f2bf_rne(oB[3]) << 16)};
+            __builtin_amdgcn_raw_buffer_store_b64(qa, ro, (xs * C + chA) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(qb, ro, (xs * C + chB) * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oA), ro, (xs * C + chA) * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oB), ro, (xs * C + chB) * 4, 0, 0);
+        }
+    };
+
+    static_for<NR>([&](auto t_tag) {                                 // input row y0 - P + t feeds output rows th = t - i, 0 <= i < k
+        constexpr int t = decltype(t_tag)::value;
+        // row t + 2 -> the buffer row t came from (it is in registers since the end of the previous step)
+        if constexpr (t + 2 < NR) dma_row(y0 - P + t + 2, t % 2);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<XW - 1>([&](auto s_tag) {                         // the pixel pair (s, s + 1)
+            constexpr int s = decltype(s_tag)::value;
+            f32x2 xv;
+            if constexpr (s % 2 == 0) xv = xp[s / 2];
+            else xv = (f32x2){xp[s / 2][1], xp[s / 2 + 1][0]};
+#pragma unroll
+            for (int th = 0; th < TH; ++th) {
+                const int i = t - th;
+                if (i < 0 || i >= KS) continue;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const int q = s - j;
+                    if (q >= 0 && q < SW && q % 2 == 0) {
+                        if ((i * KS + j) % 2) pk_fma_whi(acc[th][q / 2], xv, wp[(i * KS + j) / 2]);
+                        else pk_fma_wlo(acc[th][q / 2], xv, wp[(i * KS + j) / 2]);
+                    }
+                }
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (t + 1 < NR) {
+            // Row t + 1 has landed once at most NG vector-memory operations are outstanding: loads retire in order among loads, so
+            // row t + 2's NG DMA instructions cannot complete before row t + 1's.  Stores retire independently of loads (a store may
+            // overtake an older load), so they must NOT be added to the allowance: an earlier form that allowed NG + 2 for the
+            // row's two stores read half-landed rows under memory load.  Hence also the order: read the next row BEFORE this step's
+            // stores are issued -- the previous step's stores are old by now and the wait does not sit on fresh ones.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(t + 2 < NR ? NG : 0) : "memory");
+            read_row(std::integral_constant<int, (t + 1) % 2>{});
+        }
+        if constexpr (t >= KS - 1) finish_row(acc[t - (KS - 1)], y0 + t - (KS - 1));
+    });
+}
+
+int g_dw_cl = -1;          // tuning hook LVAE_DW_CL: 0 = never (earlier forms), 1 / 2 / 4 / 8 = force TH, -1 = heuristic
+bool g_dw_cl_read = false;
+
+template <int KS, int NW, int TH, bool BF>
+int launch_cl_th(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
+                 hipStream_t st) {
+    const int n_sx = (W + CL_SW - 1) / CL_SW, n_sy = (H + TH - 1) / TH;
+    const long grid = (long)B * n_sx * n_sy;
+    if (grid > 0x7fffffffL || (long)H * W * 64 * NW * (BF ? 2 : 4) > 0x7fffffffL) return -22;
+    hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
+                       n_sx, n_sy);
+    return (int)hipGetLastError();
+}
+
+template <int KS, int NW, bool BF>
+int launch_cl(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
+              hipStream_t st) {
+    // output rows per workgroup: the largest TH that still fills the chip's workgroup slots for whole rounds (a workgroup's time is
+    // ~ TH + k - 1 row steps plus ~3 for the weight loads and the first row)
+    const int n_sx = (W + CL_SW - 1) / CL_SW;
+    int best = 1;
+    double best_t = 1e300;
+    for (int th = 1; th <= 8; th *= 2) {
+        if (KS == 1 && th > 1) break;                                  // k = 1: nothing is shared between rows
+        // resident workgroups per CU: 3 / 4 waves per SIMD (the register budgets) and 160 KB of LDS
+        constexpr int LDSB = cl_lds_bytes<KS, NW, BF>();
+        const int by_waves = (KS == 7 && th == 8 ? 12 : 16) / NW, by_lds = (160 * 1024) / LDSB;
+        const long slots = 256L * (by_waves < by_lds ? by_waves : by_lds);
+        const long wgs = (long)B * n_sx * ((H + th - 1) / th);
+        const double t = (double)((wgs + slots - 1) / slots) * (th + KS - 1 + 3);
+        if (t < best_t * 0.999) { best_t = t; best = th; }
+    }
+    const int TH = (g_dw_cl > 0 && (KS > 1 || g_dw_cl == 1)) ? g_dw_cl : best;
+    if constexpr (KS > 1) {
+        if (TH == 8) return launch_cl_th<KS, NW, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        if (TH == 4) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        if (TH == 2) return launch_cl_th<KS, NW, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+    }
+    return launch_cl_th<KS, NW, 1, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+}
+
+template <int KS, bool BF>
+int launch_cl_c(int C, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H,
+                int W, hipStream_t st) {
+    switch (C) {
+        case 128: return launch_cl<KS, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 192: return launch_cl<KS, 3, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 256: return launch_cl<KS, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 384: return launch_cl<KS, 6, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 512: return launch_cl<KS, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+    }
+    return -22;
+}
+
+}  // namespace
+
+// Entry point for pointwise.hip's dispatchers.  Returns 1 when this kernel takes the problem (*rc = launch status), 0 otherwise.
+// Taken for C in {128, 192, 256, 384, 512}, k in {1, 3, 5, 7} and at most ONE per-channel affine after the normalisation -- a rule
+// in (C, k, which pointers are given) only, because this kernel's LayerNorm association differs from the other forms'.
+int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
+                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc) {
+    if (!g_dw_cl_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); g_dw_cl_read = true; }
+    if (g_dw_cl == 0) return 0;
+    if (ln_w && shift) return 0;
+    if (!(C == 128 || C == 192 || C == 256 || C == 384 || C == 512) || !(k == 1 || k == 3 || k == 5 || k == 7)) return 0;
+    const float* aw = ln_w ? ln_w : scale1p;
+    const float* ab = ln_w ? ln_b : shift;
+#define LVAE_CL_CASE(KS)                                                                                          \
+    case KS:                                                                                                      \
+        *rc = bf16 ? launch_cl_c<KS, true>(C, x, wt, bias, aw, ab, y, B, H, W, st)                                 \
+                   : launch_cl_c<KS, false>(C, x, wt, bias, aw, ab, y, B, H, W, st);                               \
+        return 1;
+    switch (k) {
+        LVAE_CL_CASE(1)
+        LVAE_CL_CASE(3)
+        LVAE_CL_CASE(5)
+        LVAE_CL_CASE(7)
+    }
+#undef LVAE_CL_CASE
+    return 0;
+}

@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     auto perm = [](int q) { return (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1); };        // 0,2,4,6,1,3,5,7
+#ifdef LVAE_EXP_PRIO
+    // the two workgroups of a CU get different issue priorities (told apart by their LDS allocation base), so that they drift
+    // out of phase instead of reaching their per-stage barriers together
+    if (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 6) != 0) __builtin_amdgcn_s_setprio(LVAE_EXP_PRIO);
+#endif
 
     // split-K (gridDim.y slices): this workgroup covers k16 stages [q0, q0 + nq); the slice offset goes into the buffer bases
     const int nq = d.K / 16 / (int)gridDim.y, q0 = (int)blockIdx.y * nq;
@@ -321,15 +326,27 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
         float x0 = __uint_as_float(ra[par][j][2 * h]), x1 = __uint_as_float(ra[par][j][2 * h + 1]);
         if (AGELU) { x0 = gelu_erf(x0); x1 = gelu_erf(x1); }
         unsigned hi, mid, lo;
+#ifdef LVAE_EXP_NOSPLIT            // experiment (wrong results): what the operand split costs inside the main loop
+        hi = ra[par][j][2 * h]; mid = ra[par][j][2 * h + 1]; lo = hi;
+#else
         split_pair(x0, x1, hi, mid, lo);
+#endif
         asm volatile("" : "+v"(hi), "+v"(mid), "+v"(lo));
         sa[0][h] = hi; sa[1][h] = mid; sa[2][h] = lo;
     };
     auto store_a = [&](char* st, int j) {
+#ifdef LVAE_EXP_NOSTORE
+        if (d.M > 0) return;
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(u32x2*)(st + a_st[j] + p * 32) = sa[p];
     };
-    auto store_w = [&](char* st, int par, int j) { *(u32x4*)(st + w_st[j]) = rb[par][j]; };
+    auto store_w = [&](char* st, int par, int j) {
+#ifdef LVAE_EXP_NOSTORE
+        if (d.M > 0) return;
+#endif
+        *(u32x4*)(st + w_st[j]) = rb[par][j];
+    };
     // load order of one register set: A0, W0, W1, A1, W2, W3, W4 -- the same in the prologue and in the loop (vmcnt bookkeeping)
     auto load_set = [&](int par, int q) {
         load_a(par, 0, q);
@@ -352,9 +369,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
 
     bf16x8 af[2][3], bf[2][3];
 #ifdef LVAE_X3V2_TRACE
+#if LVAE_X3V2_TRACE == 2           // every workgroup records: [block][8 header + 4 * 256 stamps]; header: start, end, HW_ID, XCC_ID
+    const bool tracing = tid == 0;
+    long* const tbuf = lvae_trace_buf + (long)blockIdx.x * (8 + 4 * 256);
+    if (tracing) {
+        tbuf[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tbuf[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tbuf[4] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    }
+#else
     const bool tracing = blockIdx.x == (unsigned)(n_tiles / 2 + 8) && tid == 0;
+    long* const tbuf = lvae_trace_buf - 8;
+#endif
     long tstamp[4] = {0, 0, 0, 0};
-    if (tracing) lvae_trace_buf[120] = __builtin_readcyclecounter();
+    if (tracing) lvae_trace_buf[LVAE_X3V2_TRACE == 2 ? (long)blockIdx.x * (8 + 4 * 256) : 120] = __builtin_readcyclecounter();
 #endif
     // one k16 stage: compute on stage PAR, write tile q+1 from register set PAR^1 into the other stage, reload that set with q+3
     auto body = [&](auto par_tag, int q) {
@@ -413,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
         __syncthreads();
         X3_STAMP(3);
 #ifdef LVAE_X3V2_TRACE
-        if (tracing && q < 28) for (int z = 0; z < 4; ++z) lvae_trace_buf[q * 4 + z] = tstamp[z];
+        if (tracing && q < (LVAE_X3V2_TRACE == 2 ? 256 : 28)) for (int z = 0; z < 4; ++z) tbuf[8 + q * 4 + z] = tstamp[z];
 #endif
     };
     for (int q = 0; q < nq; q += 2) {
@@ -421,11 +449,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc
         body(std::integral_constant<int, 1>{}, q + 1);
     }
 #ifdef LVAE_X3V2_TRACE
-    if (tracing) lvae_trace_buf[121] = __builtin_readcyclecounter();
+    if (tracing) lvae_trace_buf[LVAE_X3V2_TRACE == 2 ? (long)blockIdx.x * (8 + 4 * 256) + 1 : 121] = __builtin_readcyclecounter();
 #endif
     gemm_finish<C>(d, acc, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 #ifdef LVAE_X3V2_TRACE
-    if (tracing) lvae_trace_buf[122] = __builtin_readcyclecounter();
+    if (tracing) lvae_trace_buf[LVAE_X3V2_TRACE == 2 ? (long)blockIdx.x * (8 + 4 * 256) + 5 : 122] = __builtin_readcyclecounter();
 #endif
 }
 

@@ -1139,11 +1139,19 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
 
 }  // namespace
 
+// dwconv_cl.hip: the channel-per-lane form (rolling register window, weights in registers); takes the problem by (C, k) alone
+int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
+                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc);
+
 extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                                   const float* shift, const float* scale1p, float* y, int B, int H, int W, int C, int k,
                                   void* stream) {
     if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
     if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    {
+        int rc = 0;
+        if (lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 0, (hipStream_t)stream, &rc)) return rc;
+    }
     static bool env_read = false;
     if (!env_read) {
         const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e);
@@ -1202,6 +1210,10 @@ extern "C" int lvae_dwconv_ln_bf16(const void* x, const float* wt, const float* 
     if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
     if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
     hipStream_t st = (hipStream_t)stream;
+    {
+        int rc = 0;
+        if (lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 1, st, &rc)) return rc;
+    }
     {
         static bool t2_read = false;
         if (!t2_read) { const char* e = getenv("LVAE_DW_T2"); if (e) g_dw_t2 = atoi(e); t2_read = true; }

@@ -196,6 +196,62 @@ def test_dwconv_ln(L, C, k, B, H, W):
     assert (out.double() - y2).abs().max().item() < 3e-5
 
 
+def test_dwconv_ln_beside_gemms(L):
+    """The channel-per-lane depthwise+LN kernel on one stream while split-K bf16x3 GEMMs (MFMA) run on another: every output must
+    equal the kernel's output when it runs alone.  Guards the packed-FMA operand form of dwconv_cl.hip: with the weight pair as
+    src1 and `op_sel:[0,1,0]` the low lanes were occasionally wrong beside MFMA kernels (20-30 % of such launches on MI355X)."""
+    import ctypes
+    from lvae import _native
+    from lvae.models.base import pack_bf16x3
+    g = torch.Generator().manual_seed(3)
+    dw_cases = []
+    for (B, H, W, C, k) in [(1, 16, 24, 384, 7), (1, 8, 12, 512, 3), (1, 32, 48, 256, 7), (1, 16, 24, 512, 5), (1, 32, 48, 192, 7)]:
+        dw_cases.append(dict(B=B, H=H, W=W, C=C, k=k, x=torch.randn(B, H, W, C, generator=g).cuda(),
+                             wp=(torch.randn(k * k, C, generator=g) / k).cuda(), b=torch.randn(C, generator=g).cuda(),
+                             sh=torch.randn(C, generator=g).cuda(), sc=(1 + 0.3 * torch.randn(C, generator=g)).cuda()))
+
+    def dw(c, y, st):
+        assert L.lvae_dwconv_ln_f32(c['x'].data_ptr(), c['wp'].data_ptr(), c['b'].data_ptr(), None, None, c['sh'].data_ptr(),
+                                    c['sc'].data_ptr(), y.data_ptr(), c['B'], c['H'], c['W'], c['C'], c['k'],
+                                    ctypes.c_void_p(st.cuda_stream)) == 0
+
+    gm_cases = []
+    for (M, N, K, S) in [(384, 512, 1024, 8), (96, 1024, 512, 4), (384, 1536, 512, 4), (1536, 384, 768, 2), (384, 512, 1536, 4)]:
+        Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        gm_cases.append(dict(M=M, N=N, K=K, S=S, A=torch.randn(M, K, generator=g).cuda(), Wt=Wt, W3=pack_bf16x3(Wt),
+                             bias=torch.randn(N, generator=g).cuda()))
+    ws = torch.empty(max(c['S'] * c['M'] * c['N'] for c in gm_cases), device='cuda')
+    cnt = torch.zeros(8192, dtype=torch.int32, device='cuda')
+
+    def gm(c, out, st):
+        d = _native.GemmDesc()
+        d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = c['A'].data_ptr(), c['K'], c['K'], c['Wt'].data_ptr(), c['W3'].data_ptr(), c['K']
+        d.bias, d.out, d.ldo, d.M, d.N, d.K, d.epi, d.prec = c['bias'].data_ptr(), out.data_ptr(), c['N'], c['M'], c['N'], c['K'], 1, 2
+        d.ksplit, d.ws, d.cnt = c['S'], ws.data_ptr(), cnt.data_ptr()
+        assert L.lvae_gemm_f32(ctypes.byref(d), ctypes.c_void_p(st.cuda_stream)) == 0
+
+    cur = torch.cuda.current_stream()
+    dw_ref, gm_ref = [], []
+    for c in dw_cases:
+        y = torch.empty_like(c['x']); dw(c, y, cur); torch.cuda.synchronize(); dw_ref.append(y)
+    for c in gm_cases:
+        o = torch.empty(c['M'], c['N'], device='cuda'); gm(c, o, cur); torch.cuda.synchronize(); gm_ref.append(o)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    bad_dw = bad_gm = 0
+    for rep in range(40):
+        outs_dw, outs_gm = [], []
+        for i in range(10):
+            di, gi = (i + rep) % len(dw_cases), (i + 2 * rep) % len(gm_cases)
+            y = torch.full_like(dw_cases[di]['x'], float('nan'))
+            dw(dw_cases[di], y, s1); outs_dw.append((y, dw_ref[di]))
+            o = torch.empty(gm_cases[gi]['M'], gm_cases[gi]['N'], device='cuda')
+            gm(gm_cases[gi], o, s2); outs_gm.append((o, gm_ref[gi]))
+        torch.cuda.synchronize()
+        bad_dw += sum(0 if torch.equal(a, b) else 1 for a, b in outs_dw)
+        bad_gm += sum(0 if torch.equal(a, b) else 1 for a, b in outs_gm)
+    assert (bad_dw, bad_gm) == (0, 0)
+
+
 def test_stem(L):
     g = torch.Generator().manual_seed(1)
     B, H, W, Cout = 2, 24, 40, 192

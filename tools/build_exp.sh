@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build an experimental copy of liblvae_hip.so: tools/build_exp.sh <name> <file.hip> <extra hipcc flags...>
+# -> _bin/<name>/liblvae_hip.so (only <file.hip> is recompiled; the other objects come from the in-tree build).
+# Run a tool against it with LVAE_LIB=_bin/<name>/liblvae_hip.so (tools/microbench.py, tools/dw_bench.py honour it).
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; src=$2; shift 2
+N=$R/lossy-vae_amd/lvae/_native
+mkdir -p $R/_bin/$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $R/lossy-vae_amd/csrc/$src -o $R/_bin/$name/$src.o
+objs=""
+for o in gemm_f32.hip gemm_x3v2.hip gemm_lp.hip pointwise.hip dwconv_cl.hip rans_host.cpp; do
+  if [ "$o" = "$src" ]; then objs="$objs $R/_bin/$name/$src.o"; else objs="$objs $N/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/_bin/$name/liblvae_hip.so $objs -lpthread
+echo $R/_bin/$name/liblvae_hip.so

@@ -4,6 +4,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'lossy-vae_amd'))
 import torch
 from lvae import _native
+if os.environ.get('LVAE_LIB'):
+    _native.LIB_PATH = os.path.abspath(os.environ['LVAE_LIB'])
 L = _native.lib()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 shapes = [(8, 128, 192, 192, 1), (8, 128, 192, 192, 3), (8, 128, 192, 192, 5), (8, 128, 192, 192, 7), (8, 128, 192, 128, 7), (8, 64, 96, 384, 7), (8, 64, 96, 256, 7), (8, 32, 48, 384, 5), (8, 32, 48, 512, 5),

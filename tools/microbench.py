@@ -12,6 +12,8 @@ import torch  # noqa: E402
 from lvae import _native  # noqa: E402
 from lvae._native import GemmDesc  # noqa: E402
 
+if os.environ.get('LVAE_LIB'):            # experimental build (tools/build_exp.sh)
+    _native.LIB_PATH = os.path.abspath(os.environ['LVAE_LIB'])
 L = _native.lib()
 
 
