@@ -6,8 +6,9 @@
 // is bound by LDS fragment reads (17 ds_read_b128 per 56 packed FMAs: DESIGN.md 5b).  Here the roles are swapped:
 //   * a lane owns ONE CHANNEL of an 8-pixel-wide column strip and keeps its k*k weights in registers (49 VGPRs at k = 7); a wave is
 //     64 channels of one strip, a workgroup the C/64 waves of that strip.  Two horizontally adjacent output pixels share one
-//     v_pk_fma_f32 (the weight is broadcast to both halves with op_sel); the pixel pairs that start at an odd column are
-//     assembled with two moves -- 64-bit operands must be even-aligned;
+//     v_pk_fma_f32 (the weight is broadcast to both halves with op_sel_hi; at k = 7 every second weight sits in a high half and is
+//     applied with two scalar FMAs -- see pk_fma_wlo); the pixel pairs that start at an odd column are assembled with two moves --
+//     64-bit operands must be even-aligned;
 //   * a workgroup produces a tile of 8 x TH output pixels: the TH + k - 1 input rows are visited ONCE, top to bottom (8 + k - 1
 //     pixels per lane and row), and each feeds the up to k output rows it
 //     belongs to; TH x 8 accumulators per lane.  The whole tile is straight-line code (every register index static, no phi copies).
@@ -22,10 +23,10 @@
 // TH (8, 4, 2 or 1 output rows per workgroup; k - 1 halo rows are re-read per tile, from L2) only changes the parallelism, never an
 // output bit, so the launcher picks it from the map size.
 //
-// Arithmetic: the conv chain is the earlier kernels' (same bits); the LayerNorm uses THIS kernel's association (8 channels in a
-// lane: ((a0+a1)+(a2+a3)) + ((b0+b1)+(b2+b3)), 8 lanes by xor 1, xor 2, half-mirror, then the waves in ascending order) and
-// rstd = v_rsq_f32 refined by one Newton step (the earlier forms: 1 / sqrtf), so the operator is dispatched to this kernel by (C, k)
-// alone -- never by batch or map size: batch-of-8 == 8 single images, and the encoder and the decoder see the same bits.
+// Arithmetic: the conv chain is the earlier kernels' (same bits); the LayerNorm uses THIS kernel's association (per wave: mean and
+// centred sum of squares of its 64 channels -- 8 channels in a lane, 8 lanes by xor 1, xor 2, half-mirror -- merged over the waves in
+// ascending order by the parallel-variance identity) and rstd = v_rsq_f32 refined by one Newton step (the earlier forms: 1 / sqrtf),
+// so the operator is dispatched to this kernel by (C, k) alone -- never by batch or map size: batch-of-8 == 8 single images, and the encoder and the decoder see the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -48,23 +49,38 @@ __device__ __forceinline__ float sum8(float s) {          // total over the 8 la
     s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x141, 0xF, 0xF, true));      // row_half_mirror
     return s;
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0): it would
+// wait, twice per output row, for the row DMA issued a moment ago and for the previous row's stores.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ unsigned f2bf_rne(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// acc += x * w.lo (or w.hi) in both halves: v_pk_fma_f32 with the weight broadcast by op_sel.  Inline asm because hipcc gives every
-// broadcast scalar a 64-bit register pair of its own (the odd half stays empty): 98 instead of 50 registers for the 7 x 7 weights.
-// The weight pair is src0 in the high-half form ON PURPOSE.  With the pair as src1 (`op_sel:[0,1,0]`: the LOW lane selects the HIGH
-// dword of src1 -- a form hipcc itself never emits for packed f32) the low lane's result was occasionally wrong on MI355X whenever
-// MFMA kernels shared the CUs: 20-30 % of the launches beside split-K GEMMs on a second stream had a few pixels off (always even
-// columns, i.e. low lanes), 0 of 400 alone, 0 of 400 with the pair as src0 (`op_sel:[1,0,0]`), 0 of 400 with a swapped copy and no
-// low-lane selection.  tests/test_gpu_kernels.py::test_dwconv_ln_beside_gemms keeps watching it.
+// acc += x * w in both halves (two adjacent pixels): v_pk_fma_f32 with the weight in the LOW half of its register pair, broadcast by
+// op_sel_hi (the high lane selects the low dword: the form hipcc itself emits for scalar broadcasts).  Inline asm because hipcc gives
+// every broadcast scalar a 64-bit pair of its own; at k = 7 the 49 weights must share 25 pairs (98 registers would cost the third wave
+// per SIMD), and the weights in the HIGH halves are applied with two scalar v_fmac_f32 instead:
+// **a packed op whose LOW lane selects the HIGH dword of an operand (`op_sel` = 1) returned occasional wrong low-lane results on MI355X
+// whenever MFMA kernels shared the CUs.**  With the weight pair as src1 (`op_sel:[0,1,0]`) 20-30 % of the launches beside split-K GEMMs
+// on a second stream had a few pixels off (always even columns = low lanes; run-to-run different bitstreams in the bf16x3 model only,
+// whose GEMMs are MFMA-dense enough), 0 of 400 alone; as src0 (`op_sel:[1,0,0]`) 0 of 1600 on four boxes but 359 of 400 on a fifth.
+// hipcc never emits that form for packed f32 arithmetic; its `v_pk_mov_b32 ... op_sel:[1,0]` for a pair assembled from two odd halves
+// is the same selection, so those pairs are assembled with two v_mov_b32 here.  tests/test_gpu_kernels.py::test_dwconv_ln_beside_gemms.
 __device__ __forceinline__ void pk_fma_wlo(f32x2& a, f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(x), "v"(w));
 }
-__device__ __forceinline__ void pk_fma_whi(f32x2& a, f32x2 x, f32x2 w) {
-    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(x), "v"(w));
+__device__ __forceinline__ void fmac_whi(f32x2& a, float x0, float x1, f32x2 w) {
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(a[0]) : "v"(x0), "v"(w[1]));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(a[1]) : "v"(x1), "v"(w[1]));
+}
+__device__ __forceinline__ f32x2 pair_of(float lo, float hi) {     // two plain moves (never v_pk_mov_b32 with op_sel)
+    f32x2 p;
+    asm("v_mov_b32 %0, %1" : "=v"(p[0]) : "v"(lo));
+    asm("v_mov_b32 %0, %1" : "=v"(p[1]) : "v"(hi));
+    return p;
 }
 
 // static_for<N>(f): f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The row / pixel loops MUST be unrolled (every
@@ -81,7 +97,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int CL_SW = 8;                    // output pixels per lane along W
 constexpr int CL_TILE = 8 * 96;             // floats of a wave's transpose tile: 8 pixels x 384 B (64 channels + pad: conflict-free b128 reads)
 
-// amdgpu_waves_per_eu pins the register budget: three waves per SIMD (168 VGPRs) for the k = 7, TH = 8 tiles, four (128) for the others.
+// amdgpu_waves_per_eu pins the register budget: three waves per SIMD (168 VGPRs) for the k >= 5, TH = 8 tiles, four (128) for the others.
 // Measured at k = 7, C = 192: 85 us at three waves, 106 us when two more registers push the kernel to two.
 template <int KS, bool BF> struct ClGeom {
     static constexpr int XW = CL_SW + KS - 1;                       // input pixels per lane and row
@@ -90,10 +106,10 @@ template <int KS, bool BF> struct ClGeom {
     static constexpr int ROWF = NG * 256;                           // floats of one row buffer (NG KiB)
 };
 
-template <int KS, int NW, bool BF> constexpr int cl_lds_bytes() { return (NW * (CL_TILE + 2 * ClGeom<KS, BF>::ROWF) + 128 + 128 * NW) * 4; }
+template <int KS, int NW, bool BF> constexpr int cl_lds_bytes() { return (NW * (CL_TILE + 2 * ClGeom<KS, BF>::ROWF) + 256 + 128 * NW) * 4; }
 // waves per SIMD the kernel is compiled for: what the registers allow (above), capped by what 160 KB of LDS lets reside on a CU
 template <int KS, int NW, int TH, bool BF> constexpr int cl_waves() {
-    const int by_regs = (KS == 7 && TH == 8) ? 3 : 4;
+    const int by_regs = (KS >= 5 && TH == 8) ? 3 : 4;              // k = 5: 25 unpacked weights = 50 registers too
     const int by_lds = ((160 * 1024) / cl_lds_bytes<KS, NW, BF>()) * NW / 4;
     return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
 }
@@ -101,17 +117,17 @@ template <int KS, int NW, int TH, bool BF> constexpr int cl_waves() {
 template <int KS, int NW, int TH, bool BF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_waves<KS, NW, TH, BF>(), cl_waves<KS, NW, TH, BF>()))) void dwconv_ln_cl_kernel(
     const void* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ aw,
-    const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy) {
+    const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy, int tpw) {
     using G = ClGeom<KS, BF>;
     constexpr int C = 64 * NW, P = (KS - 1) / 2, SW = CL_SW, XW = G::XW, ES = BF ? 2 : 4, KK = KS * KS, NR = TH + KS - 1;
     constexpr int NG = G::NG, ROWF = G::ROWF, PPI = G::PPI;
     static_assert(XW % 2 == 0, "pixel pairs");
-    // per wave: the LayerNorm transpose tile and two row buffers; then the partial sums [stat][pixel][wave (8)] and the affine parameters
+    // per wave: the LayerNorm transpose tile and two row buffers; then the waves' statistics [row parity][pixel][wave (8)][mean, M2] and the affine parameters
     constexpr int WAVEF = CL_TILE + 2 * ROWF;
-    __shared__ __attribute__((aligned(16))) float lds[NW * WAVEF + 2 * 8 * 8 + 2 * C];
-    static_assert(sizeof(float) * (NW * WAVEF + 2 * 8 * 8 + 2 * C) == cl_lds_bytes<KS, NW, BF>(), "LDS size formula");
+    __shared__ __attribute__((aligned(16))) float lds[NW * WAVEF + 2 * 8 * 8 * 2 + 2 * C];
+    static_assert(sizeof(float) * (NW * WAVEF + 2 * 8 * 8 * 2 + 2 * C) == cl_lds_bytes<KS, NW, BF>(), "LDS size formula");
     float* const red = lds + NW * WAVEF;
-    float* const prm = red + 2 * 8 * 8;
+    float* const prm = red + 2 * 8 * 8 * 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p8 = lane >> 3, blk = lane & 7;          // LayerNorm layout: pixel of the strip, 4-channel block (and block + 8)
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
     const long b = wg / ((long)n_sx * n_sy);
     const int c0 = 64 * wave + lane;                   // conv layout: this lane's channel
     const int x0 = sx * SW;
-    const int y0 = sy * TH;
+    int y0 = sy * tpw * TH;                            // this workgroup: tpw vertically consecutive tiles of TH rows (n_sy counts workgroups)
     const int rowbytes = W * C * ES;
     const char* const xin = (const char*)x + b * (long)H * rowbytes;
     char* const yout = (char*)y + b * (long)H * rowbytes;
@@ -147,23 +163,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rowbuf + buf * ROWF + g * 256), 16,
                                                      dvoff0 + g * PPI * C * ES, 0, 0, 0);
     };
-    if constexpr (NR > 0) dma_row(y0 - P, 0);
-    if constexpr (NR > 1) dma_row(y0 - P + 1, 1);
-
-    f32x2 wp[(KK + 1) / 2];                            // tap t in wp[t / 2][t % 2]: the FMAs broadcast either half with op_sel
+    // k = 7: tap t in wp[t / 2][t % 2] (two weights per register pair); k <= 5: tap t in wp[t][0] (every weight broadcastable)
+    constexpr bool PACKW = KS == 7;
+    f32x2 wp[PACKW ? (KK + 1) / 2 : KK];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) wp[t / 2][t % 2] = wt[(long)t * C + c0];
-    if (KK % 2) wp[KK / 2][1] = 0.f;
+    for (int t = 0; t < KK; ++t) {
+        if constexpr (PACKW) wp[t / 2][t % 2] = wt[(long)t * C + c0];
+        else wp[t] = (f32x2){wt[(long)t * C + c0], 0.f};
+    }
+    if (PACKW && KK % 2) wp[KK / 2][1] = 0.f;
     const float bias1 = bias[c0];
     prm[tid] = aw ? aw[tid] : 1.f;                     // blockDim.x == C
     prm[C + tid] = ab ? ab[tid] : 0.f;
     const int chA = 64 * wave + 4 * blk, chB = chA + 32;
 
     f32x2 acc[TH][SW / 2];
-#pragma unroll
-    for (int th = 0; th < TH; ++th)
-#pragma unroll
-        for (int q = 0; q < SW / 2; ++q) acc[th][q] = (f32x2){bias1, bias1};
 
     // LDS -> registers: the row buffer is read with inline asm (hipcc would guard every LDS load that may alias an LDS-DMA in flight with
     // s_waitcnt vmcnt(0), i.e. wait for the row AFTER the one being read); the vmcnt waits below are exact.  bf16 maps: d16_hi loads
@@ -184,51 +198,57 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // the weights and row 0 have landed (row 1 may still be in flight)
-    if constexpr (NR > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_row(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights are consumed by inline asm: no compiler-placed wait covers them
     __syncthreads();                                   // prm visible
     const float inv_c = 1.0f / (float)C;
     float* const tile = lds + wave * WAVEF;
 
-    // LayerNorm + affine + store of one finished output row (absolute row ya)
-    auto finish_row = [&](const f32x2 (&a)[SW / 2], int ya) {
+    // LayerNorm + affine + store of a finished output row, in two phases around ONE workgroup barrier.  ln_local (right after the
+    // row's last taps): transpose through the wave's tile, then the statistics of THIS wave's 64 channels -- mean_w and the centred
+    // sum of squares M2_w -- go to LDS.  ln_finish (after the barrier, placed a few pixel steps into the NEXT row's taps so that the
+    // LDS round trips and the barrier skew hide behind FMAs): the waves' statistics are merged with the parallel-variance identity
+    // M2 = sum_w M2_w + 64 sum_w (mean_w - mean)^2 (no cancellation, unlike E[x^2] - mean^2), fixed order over the waves.
+    f32x4 lnA, lnB;                                    // the row's values minus mean_w, LayerNorm layout
+    float ln_mw;
+    auto ln_local = [&](const f32x2 (&a)[SW / 2], int par) {
 #pragma unroll
         for (int q = 0; q < SW; ++q) tile[q * 96 + lane] = a[q / 2][q % 2];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-private tile: LDS executes a wave's accesses in order
         f32x4 vA = *(const f32x4*)(tile + p8 * 96 + 4 * blk), vB = *(const f32x4*)(tile + p8 * 96 + 32 + 4 * blk);
         float s = ((vA[0] + vA[1]) + (vA[2] + vA[3])) + ((vB[0] + vB[1]) + (vB[2] + vB[3]));
         s = sum8(s);
-        if (blk == 0) red[p8 * 8 + wave] = s;
-        __syncthreads();
-        float tot = red[p8 * 8];
+        const float mw = s * (1.0f / 64.0f);
+        float m2 = 0.f;
 #pragma unroll
-        for (int v = 1; v < NW; ++v) tot += red[p8 * 8 + v];
-        const float mean = tot * inv_c;
-        float sq = 0.f;
+        for (int e = 0; e < 4; ++e) { vA[e] -= mw; m2 = fmaf(vA[e], vA[e], m2); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vA[e] -= mean; sq = fmaf(vA[e], vA[e], sq); }
+        for (int e = 0; e < 4; ++e) { vB[e] -= mw; m2 = fmaf(vB[e], vB[e], m2); }
+        m2 = sum8(m2);
+        if (blk == 0) *(f32x2*)(red + par * 128 + (p8 * 8 + wave) * 2) = (f32x2){mw, m2};
+        lnA = vA; lnB = vB; ln_mw = mw;
+    };
+    auto ln_finish = [&](int ya, int par) {
+        const float* r = red + par * 128 + p8 * 16;                    // [wave][mean_w, M2_w]
+        float msum = r[0], m2 = r[1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vB[e] -= mean; sq = fmaf(vB[e], vB[e], sq); }
-        sq = sum8(sq);
-        if (blk == 0) red[64 + p8 * 8 + wave] = sq;
-        __syncthreads();
-        float totq = red[64 + p8 * 8];
+        for (int v = 1; v < NW; ++v) { msum += r[2 * v]; m2 += r[2 * v + 1]; }
+        const float mean = msum * (1.0f / (float)NW);
+        float dev = 0.f;
 #pragma unroll
-        for (int v = 1; v < NW; ++v) totq += red[64 + p8 * 8 + v];
+        for (int v = 0; v < NW; ++v) { const float dm = r[2 * v] - mean; dev = fmaf(dm, dm, dev); }
         // the affine parameters come from LDS: in registers across the tap loop they would cost 16 VGPRs (what separates the k = 7,
         // TH = 8 instance from three waves per SIMD), and global loads here would share the in-order vmcnt with the row DMA
         const f32x4 awA = *(const f32x4*)(prm + chA), awB = *(const f32x4*)(prm + chB);
         const f32x4 abA = *(const f32x4*)(prm + C + chA), abB = *(const f32x4*)(prm + C + chB);
-        const float var = fmaf(totq, inv_c, 1e-6f);                    // >= 1e-6: no special cases for the reciprocal square root
+        const float var = fmaf(fmaf(64.0f, dev, m2), inv_c, 1e-6f);    // >= 1e-6: no special cases for the reciprocal square root
         float rstd = __builtin_amdgcn_rsqf(var);
         rstd = rstd * fmaf(-0.5f * var, rstd * rstd, 1.5f);            // one Newton step
+        const float sh = ln_mw - mean;                                 // x - mean = (x - mean_w) + (mean_w - mean)
         const int xs = x0 + p8;
         const __amdgpu_buffer_rsrc_t ro = row_rsrc(yout, ya);
         f32x4 oA, oB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { oA[e] = fmaf(vA[e] * rstd, awA[e], abA[e]); oB[e] = fmaf(vB[e] * rstd, awB[e], abB[e]); }
+        for (int e = 0; e < 4; ++e) { oA[e] = fmaf((lnA[e] + sh) * rstd, awA[e], abA[e]); oB[e] = fmaf((lnB[e] + sh) * rstd, awB[e], abB[e]); }
         if (BF) {
             const u32x2 qa = {f2bf_rne(oA[0]) | (f2bf_rne(oA[1]) << 16), f2bf_rne(oA[2]) | (f2bf_rne(oA[3]) << 16)};
             const u32x2 qb = {f2bf_rne(oB[0]) | (f2bf_rne(oB[1]) << 16), f2bf_rne(oB[2]) | (f2bf_rne(oB[3]) << 16)};
@@ -239,7 +259,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oB), ro, (xs * C + chB) * 4, 0, 0);
         }
     };
+    constexpr int LN_AT = 3;                           // pixel step of the next row at which the previous row's LayerNorm is finished
 
+    // The k x k weights (49 dword loads per lane, as many vector-memory instructions as 12 rows of DMA) are loaded once per workgroup and
+    // serve tpw tiles; the launcher picks tpw so that the workgroups still fill the chip in whole rounds.
+    for (int it = 0; it < tpw && y0 < H; ++it, y0 += TH) {
+    dma_row(y0 - P, 0);
+    if constexpr (NR > 1) dma_row(y0 - P + 1, 1);
+#pragma unroll
+    for (int th = 0; th < TH; ++th)
+#pragma unroll
+        for (int q = 0; q < SW / 2; ++q) acc[th][q] = (f32x2){bias1, bias1};
+    // row 0 has landed (row 1 may still be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR > 1 ? NG : 0) : "memory");
+    read_row(std::integral_constant<int, 0>{});
     static_for<NR>([&](auto t_tag) {                                 // input row y0 - P + t feeds output rows th = t - i, 0 <= i < k
         constexpr int t = decltype(t_tag)::value;
         // row t + 2 -> the buffer row t came from (it is in registers since the end of the previous step)
@@ -247,9 +280,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
         __builtin_amdgcn_sched_barrier(0);
         static_for<XW - 1>([&](auto s_tag) {                         // the pixel pair (s, s + 1)
             constexpr int s = decltype(s_tag)::value;
+            if constexpr (s == LN_AT && t - 1 >= KS - 1) {
+                lds_barrier();
+                ln_finish(y0 + t - 1 - (KS - 1), (t - 1) % 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float x0 = xp[s / 2][s % 2], x1 = xp[(s + 1) / 2][(s + 1) % 2];
             f32x2 xv;
             if constexpr (s % 2 == 0) xv = xp[s / 2];
-            else xv = (f32x2){xp[s / 2][1], xp[s / 2 + 1][0]};
+            else xv = pair_of(x0, x1);
 #pragma unroll
             for (int th = 0; th < TH; ++th) {
                 const int i = t - th;
@@ -258,8 +297,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
                 for (int j = 0; j < KS; ++j) {
                     const int q = s - j;
                     if (q >= 0 && q < SW && q % 2 == 0) {
-                        if ((i * KS + j) % 2) pk_fma_whi(acc[th][q / 2], xv, wp[(i * KS + j) / 2]);
-                        else pk_fma_wlo(acc[th][q / 2], xv, wp[(i * KS + j) / 2]);
+                        const int tap = i * KS + j;
+                        if (!PACKW) pk_fma_wlo(acc[th][q / 2], xv, wp[tap]);
+                        else if (tap % 2 == 0) pk_fma_wlo(acc[th][q / 2], xv, wp[tap / 2]);
+                        else fmac_whi(acc[th][q / 2], x0, x1, wp[tap / 2]);
                     }
                 }
             }
@@ -268,55 +309,66 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
         if constexpr (t + 1 < NR) {
             // Row t + 1 has landed once at most NG vector-memory operations are outstanding: loads retire in order among loads, so
             // row t + 2's NG DMA instructions cannot complete before row t + 1's.  Stores retire independently of loads (a store may
-            // overtake an older load), so they must NOT be added to the allowance: an earlier form that allowed NG + 2 for the
-            // row's two stores read half-landed rows under memory load.  Hence also the order: read the next row BEFORE this step's
-            // stores are issued -- the previous step's stores are old by now and the wait does not sit on fresh ones.
+            // overtake an older load), so they must NOT be added to the allowance: an earlier form that allowed NG + 2 for a row's
+            // two stores read half-landed rows under memory load.
+            // (Reading the row pixel by pixel behind the taps, each into the register of the pixel that just died, was tried: no gain.)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(t + 2 < NR ? NG : 0) : "memory");
             read_row(std::integral_constant<int, (t + 1) % 2>{});
         }
-        if constexpr (t >= KS - 1) finish_row(acc[t - (KS - 1)], y0 + t - (KS - 1));
+        if constexpr (t >= KS - 1) ln_local(acc[t - (KS - 1)], t % 2);
     });
+    lds_barrier();
+    ln_finish(y0 + TH - 1, (NR - 1) % 2);
+    lds_barrier();                                     // the statistics buffers are free for the next tile
+    }
 }
 
-int g_dw_cl = -1;          // tuning hook LVAE_DW_CL: 0 = never (earlier forms), 1 / 2 / 4 / 8 = force TH, -1 = heuristic
+int g_dw_cl = -1;          // tuning hook LVAE_DW_CL: 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 2 / 4 / 8) = force, -1 = heuristic
 bool g_dw_cl_read = false;
 
 template <int KS, int NW, int TH, bool BF>
 int launch_cl_th(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
-                 hipStream_t st) {
-    const int n_sx = (W + CL_SW - 1) / CL_SW, n_sy = (H + TH - 1) / TH;
+                 int tpw, hipStream_t st) {
+    const int n_sx = (W + CL_SW - 1) / CL_SW, n_ty = (H + TH - 1) / TH, n_sy = (n_ty + tpw - 1) / tpw;
     const long grid = (long)B * n_sx * n_sy;
     if (grid > 0x7fffffffL || (long)H * W * 64 * NW * (BF ? 2 : 4) > 0x7fffffffL) return -22;
     hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
-                       n_sx, n_sy);
+                       n_sx, n_sy, tpw);
     return (int)hipGetLastError();
 }
 
 template <int KS, int NW, bool BF>
 int launch_cl(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
               hipStream_t st) {
-    // output rows per workgroup: the largest TH that still fills the chip's workgroup slots for whole rounds (a workgroup's time is
-    // ~ TH + k - 1 row steps plus ~3 for the weight loads and the first row)
+    // Output rows per tile (TH) and tiles per workgroup (tpw): the pair with the least estimated time.  A workgroup costs ~3 row
+    // steps for its weights plus, per tile, TH + k - 1 row steps and ~2 for the first rows' latency; the chip runs `slots`
+    // workgroups at a time (3 / 4 waves per SIMD -- the register budgets -- and 160 KB of LDS per CU), in whole rounds.
+    constexpr int LDSB = cl_lds_bytes<KS, NW, BF>();
     const int n_sx = (W + CL_SW - 1) / CL_SW;
-    int best = 1;
+    int best_th = 1, best_tpw = 1;
     double best_t = 1e300;
     for (int th = 1; th <= 8; th *= 2) {
         if (KS == 1 && th > 1) break;                                  // k = 1: nothing is shared between rows
-        // resident workgroups per CU: 3 / 4 waves per SIMD (the register budgets) and 160 KB of LDS
-        constexpr int LDSB = cl_lds_bytes<KS, NW, BF>();
-        const int by_waves = (KS == 7 && th == 8 ? 12 : 16) / NW, by_lds = (160 * 1024) / LDSB;
+        const int by_waves = (KS >= 5 && th == 8 ? 12 : 16) / NW, by_lds = (160 * 1024) / LDSB;
         const long slots = 256L * (by_waves < by_lds ? by_waves : by_lds);
-        const long wgs = (long)B * n_sx * ((H + th - 1) / th);
-        const double t = (double)((wgs + slots - 1) / slots) * (th + KS - 1 + 3);
-        if (t < best_t * 0.999) { best_t = t; best = th; }
+        const int n_ty = (H + th - 1) / th;
+        // (tpw > 1 only pays at k = 1, where a tile is one row step: measured 63 -> 50 us on the 128 x 192 map; for k >= 3 it was
+        //  within noise at best -- the weight loads are not what bounds the kernel -- and cost 15 % where it unbalanced the rounds)
+        for (int tpw = 1; tpw <= (KS == 1 ? 8 : 1); ++tpw) {
+            const long wgs = (long)B * n_sx * ((n_ty + tpw - 1) / tpw);
+            const double t = (double)((wgs + slots - 1) / slots) * (3 + tpw * (th + KS - 1 + 2));
+            if (t < best_t * 0.999) { best_t = t; best_th = th; best_tpw = tpw; }
+            if (tpw >= n_ty) break;
+        }
     }
-    const int TH = (g_dw_cl > 0 && (KS > 1 || g_dw_cl == 1)) ? g_dw_cl : best;
+    int TH = best_th, tpw = best_tpw;
+    if (g_dw_cl > 0 && (KS > 1 || g_dw_cl % 10 == 1)) { TH = g_dw_cl % 10; tpw = g_dw_cl / 10 > 0 ? g_dw_cl / 10 : 1; }   // hook: 10 * tpw + TH
     if constexpr (KS > 1) {
-        if (TH == 8) return launch_cl_th<KS, NW, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        if (TH == 4) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        if (TH == 2) return launch_cl_th<KS, NW, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        if (TH == 8) return launch_cl_th<KS, NW, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH == 4) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH == 2) return launch_cl_th<KS, NW, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
     }
-    return launch_cl_th<KS, NW, 1, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+    return launch_cl_th<KS, NW, 1, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
 }
 
 template <int KS, bool BF>

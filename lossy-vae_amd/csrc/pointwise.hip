@@ -180,628 +180,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const void* __restrict__
     }
 }
 
-// Tiled, software-pipelined form of the same operator for the large C = 128 / 192 maps (stride 4).  dwconv_ln_kernel re-reads every
-// input pixel k times per channel chunk from L2 (nothing survives in the 32 KB L1): ~27 of the 34.5 TB/s of L2 bandwidth at k = 7.
-// Here 512 threads (32 groups of 16 lanes x 4 pixels) own an 8 x 16 pixel tile; per channel chunk the tile and its (k-1) halo are
-// staged ONCE in LDS and the k x k window slides over LDS; all k*k*C weights sit in LDS too, so the compute phase issues no
-// vector-memory instruction and the global loads of the NEXT chunk (or of the next tile's first chunk: workgroups are persistent)
-// stay in flight in registers behind it (an in-order vmcnt wait on a weight load would otherwise drain them).
-// Channel -> lane ownership, tap order and the LayerNorm reduction order are dwconv_ln_kernel's: same bits, free choice per launch.
-template <int KS, int VPL>
-__global__ __launch_bounds__(512, 1) void dwconv_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                                const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                                const float* __restrict__ ln_b, const float* __restrict__ shift,
-                                                                const float* __restrict__ scale1p, float* __restrict__ y,
-                                                                int B, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
-    constexpr int LPP = 16, TW = 4, GX = 4, GY = 8, TBW = GX * TW, TBH = GY, PGB = 32;
-    constexpr int C = 4 * VPL * LPP;
-    constexpr int P = (KS - 1) / 2, LW = TBW + KS - 1, LH = TBH + KS - 1, NPIX = LW * LH;
-    constexpr int NF = (NPIX + PGB - 1) / PGB;                       // staged float4 per thread per chunk
-    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    f32x4* tile = (f32x4*)dw_lds;                                   // [NPIX][16]
-    f32x4* wl = tile + NPIX * LPP;                                  // [VPL][KS*KS][16]
-    const int tid = threadIdx.x, cl = tid % LPP, pg = tid / LPP;
-    const int gy = pg / GX, gx = pg % GX;
-    // contiguous range of tiles per workgroup (neighbouring tiles share halos in one XCD's L2: blockIdx % 8 is the XCD)
-    const int nb = gridDim.x, bq = nb / 8, br = nb % 8, xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
-    const int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + loc;
-    const int per = n_tiles / nb, rem = n_tiles % nb;
-    const int t_begin = bid * per + (bid < rem ? bid : rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
-
-    for (int e = tid; e < VPL * KS * KS * LPP; e += 512) {           // weights: wl[(v*KK + tap)*16 + lane] = wt[tap*C + 4*(lane + 16 v)]
-        const int lane = e % LPP, tap = (e / LPP) % (KS * KS), v = e / (LPP * KS * KS);
-        wl[e] = *(const f32x4*)(wt + (long)tap * C + 4 * (lane + v * LPP));
-    }
-    int lyx[NF];                                                     // halo-tile coordinates of this thread's staged pixels
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-        const int pix = pg + PGB * n, ly = pix / LW;
-        lyx[n] = (pix < NPIX) ? ((ly << 8) | (pix - ly * LW)) : -1;
-    }
-    f32x4 st[NF];
-    unsigned inmask = 0;
-    auto prefetch = [&](int t, int v) {                              // global -> registers, branch-free (clamped address + mask)
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const float* xb = x + b * (long)H * W * C + 4 * (cl + v * LPP);
-        const int h0 = ty * TBH - P, w0 = tx * TBW - P;
-        inmask = 0;
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int hh = h0 + (lyx[n] >> 8), ww = w0 + (lyx[n] & 255);
-            const bool in = lyx[n] >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            inmask |= (in ? 1u : 0u) << n;
-            st[n] = *(const f32x4*)(xb + (in ? ((long)hh * W + ww) * C : 0));
-        }
-    };
-    auto commit = [&]() {                                            // registers -> LDS tile
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-            if (lyx[n] >= 0) tile[(pg + PGB * n) * LPP + cl] = ((inmask >> n) & 1u) ? st[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-
-    if (t_begin < t_end) prefetch(t_begin, 0);
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const int h0 = ty * TBH, w0 = tx * TBW;
-        f32x4 acc[VPL][TW];
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            __syncthreads();                                         // previous chunk's readers are done (first pass: weights are in)
-            commit();
-            __syncthreads();
-            if (v + 1 < VPL) prefetch(t, v + 1);
-            else if (t + 1 < t_end) prefetch(t + 1, 0);
-            const f32x4 bv = *(const f32x4*)(bias + 4 * (cl + v * LPP));
-#pragma unroll
-            for (int q = 0; q < TW; ++q) acc[v][q] = bv;
-#pragma unroll 1
-            for (int i = 0; i < KS; ++i) {
-                const f32x4* row = tile + ((gy + i) * LW + gx * TW) * LPP + cl;
-                const f32x4* wrow = wl + (v * KS * KS + i * KS) * LPP + cl;
-                f32x4 xr[TW + KS - 1];
-#pragma unroll
-                for (int q = 0; q < TW + KS - 1; ++q) xr[q] = row[q * LPP];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const f32x4 wv = wrow[j * LPP];
-#pragma unroll
-                    for (int q = 0; q < TW; ++q) {
-                        acc[v][q][0] = fmaf(xr[q + j][0], wv[0], acc[v][q][0]);
-                        acc[v][q][1] = fmaf(xr[q + j][1], wv[1], acc[v][q][1]);
-                        acc[v][q][2] = fmaf(xr[q + j][2], wv[2], acc[v][q][2]);
-                        acc[v][q][3] = fmaf(xr[q + j][3], wv[3], acc[v][q][3]);
-                    }
-                }
-            }
-        }
-        const float inv_c = 1.0f / (float)C;
-        const int hh = h0 + gy;
-#pragma unroll
-        for (int q = 0; q < TW; ++q) {
-            float s = 0.f;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) s += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            const float mean = s * inv_c;
-            float sq = 0.f;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float dlt = acc[v][q][e] - mean;
-                    acc[v][q][e] = dlt;
-                    sq = fmaf(dlt, dlt, sq);
-                }
-            }
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
-            const int ww = w0 + gx * TW + q;
-            if (ww < W && hh < H) {
-                float* yp = y + ((b * H + hh) * (long)W + ww) * C;
-#pragma unroll
-                for (int v = 0; v < VPL; ++v) {
-                    const int c = 4 * (cl + v * LPP);
-                    f32x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][q][e] * rstd;
-                    if (ln_w) {
-                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
-                    }
-                    if (shift) {
-                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
-                    }
-                    *(f32x4*)(yp + c) = o4;
-                }
-            }
-        }
-    }
-}
-
-// Second-generation tiled form ("t2"): the same operator for every C = 64 NV layer on maps with enough tiles to fill the chip, fp32
-// or bf16 storage.  What the PMC counters said about dwconv_ln_tile_kernel (B = 8, 128x192, C = 192: 127 us): its 2048 waves are
-// parked 40 % of their cycles (s_waitcnt / barrier) and issue-stalled another 23 %, VALU-active 25 %, LDS array 32 % busy -- one
-// 512-thread workgroup per CU (116 KB of LDS) runs its phases [barrier, registers -> LDS, barrier, prefetch, taps] one after the
-// other and nothing else is resident to fill the gaps.  Here a workgroup is 256 threads on a 4 x 16 pixel tile and keeps only ONE
-// channel chunk's halo tile + weights in LDS (69 KB at k = 7, 47 KB at k = 5): two to three workgroups share a CU and overlap each
-// other's staging, barriers and global-load latency; the taps are explicit packed FMAs (v_pk_fma_f32, half the VALU issue slots;
-// each component is an fmaf, so the bits do not change).  16 lanes own a pixel group (4 pixels x all channels, chunk c of lane cl =
-// channels 4 (cl + 16 c) ..+3); the LayerNorm sums are formed in exactly the association of dwconv_ln_kernel's <.., LPP = RL, ..>
-// instance for this C (RL = 32: the first butterfly step, lane ^ 16, happens inside the lane), so all three kernels give the same
-// bits and the launcher may choose by map size.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int KS, int NV, int RL, bool BF>
-__global__ __launch_bounds__(256, 2) void dwconv_ln_t2_kernel(const void* __restrict__ x, const float* __restrict__ wt,
-                                                              const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                              const float* __restrict__ ln_b, const float* __restrict__ shift,
-                                                              const float* __restrict__ scale1p, void* __restrict__ y,
-                                                              int B, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
-    constexpr int LPP = 16, TW = 4, GX = 4, TBW = 16, TBH = 4, PGB = 16;
-    constexpr int C = 64 * NV;
-    constexpr int P = (KS - 1) / 2, LW = TBW + KS - 1, LH = TBH + KS - 1, NPIX = LW * LH, KK = KS * KS;
-    constexpr int NF = (NPIX + PGB - 1) / PGB;                       // staged pixels per thread per chunk
-    constexpr int NWF = (KK + PGB - 1) / PGB;                        // staged weight taps per thread per chunk
-    static_assert(RL == 16 || (RL == 32 && NV % 2 == 0), "reference lane count");
-    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    f32x4* tile = (f32x4*)dw_lds;                                   // [NPIX][16]
-    f32x4* wl = tile + NPIX * LPP;                                  // [KK][16]
-    const int tid = threadIdx.x, cl = tid % LPP, pg = tid / LPP;
-    const int gy = pg / GX, gx = pg % GX;
-    const int nb = gridDim.x, bq = nb / 8, br = nb % 8, xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
-    const int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + loc;
-    const int per = n_tiles / nb, rem = n_tiles % nb;
-    const int t_begin = bid * per + (bid < rem ? bid : rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
-
-    f32x4 st[NF], sw[NWF];
-    unsigned inmask = 0;
-    auto prefetch = [&](int t, int v) {                              // global -> registers, branch-free (clamped address + mask)
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const long xb = b * (long)H * W * C + 4 * (cl + v * LPP);
-        const int h0 = ty * TBH - P, w0 = tx * TBW - P;
-        inmask = 0;
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int pix = pg + PGB * n, ly = pix / LW, lx = pix - ly * LW;     // halo-tile coordinates (recomputed: registers are scarce)
-            const int hh = h0 + ly, ww = w0 + lx;
-            const bool in = pix < NPIX && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            inmask |= (in ? 1u : 0u) << n;
-            st[n] = ld4<BF>(x, xb + (in ? ((long)hh * W + ww) * C : 0));
-        }
-#pragma unroll
-        for (int n = 0; n < NWF; ++n) {
-            const int tap = pg + PGB * n;
-            sw[n] = *(const f32x4*)(wt + (long)(tap < KK ? tap : 0) * C + 4 * (cl + v * LPP));
-        }
-    };
-    auto commit = [&]() {                                            // registers -> LDS
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-            if (pg + PGB * n < NPIX) tile[(pg + PGB * n) * LPP + cl] = ((inmask >> n) & 1u) ? st[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < NWF; ++n)
-            if (pg + PGB * n < KK) wl[(pg + PGB * n) * LPP + cl] = sw[n];
-    };
-
-    if (t_begin < t_end) prefetch(t_begin, 0);
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const int h0 = ty * TBH, w0 = tx * TBW;
-        f32x4 acc[NV][TW];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            __syncthreads();                                         // previous chunk's readers are done
-            commit();
-            __syncthreads();
-            if (v + 1 < NV) prefetch(t, v + 1);
-            else if (t + 1 < t_end) prefetch(t + 1, 0);
-            const f32x4 bv = *(const f32x4*)(bias + 4 * (cl + v * LPP));
-#pragma unroll
-            for (int q = 0; q < TW; ++q) acc[v][q] = bv;
-#pragma unroll 1
-            for (int i = 0; i < KS; ++i) {
-                const f32x4* row = tile + ((gy + i) * LW + gx * TW) * LPP + cl;
-                const f32x4* wrow = wl + (i * KS) * LPP + cl;
-                f32x4 xr[TW + KS - 1];
-#pragma unroll
-                for (int q = 0; q < TW + KS - 1; ++q) xr[q] = row[q * LPP];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const f32x4 wv = wrow[j * LPP];
-#pragma unroll
-                    for (int q = 0; q < TW; ++q) acc[v][q] = __builtin_elementwise_fma(xr[q + j], wv, acc[v][q]);
-                }
-            }
-        }
-        const float inv_c = 1.0f / (float)C;
-        const int hh = h0 + gy;
-#pragma unroll
-        for (int q = 0; q < TW; ++q) {
-            // per-lane partial sums in the reference kernel's order: lane c of its RL lanes adds its chunks c, c + RL, c + 2 RL, ...
-            float s;
-            if (RL == 16) {
-                s = 0.f;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) s += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
-            } else {
-                float sa = 0.f, sb = 0.f;
-#pragma unroll
-                for (int v = 0; v < NV; v += 2) {
-                    sa += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
-                    sb += (acc[v + 1][q][0] + acc[v + 1][q][1]) + (acc[v + 1][q][2] + acc[v + 1][q][3]);
-                }
-                s = sa + sb;                                         // the reference's lane ^ 16 step
-            }
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            const float mean = s * inv_c;
-            float sq;
-            if (RL == 16) {
-                sq = 0.f;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = acc[v][q][e] - mean;
-                        acc[v][q][e] = dlt;
-                        sq = fmaf(dlt, dlt, sq);
-                    }
-                }
-            } else {
-                float qa = 0.f, qb = 0.f;
-#pragma unroll
-                for (int v = 0; v < NV; v += 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float da = acc[v][q][e] - mean, db = acc[v + 1][q][e] - mean;
-                        acc[v][q][e] = da; acc[v + 1][q][e] = db;
-                        qa = fmaf(da, da, qa);
-                        qb = fmaf(db, db, qb);
-                    }
-                }
-                sq = qa + qb;
-            }
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
-            const int ww = w0 + gx * TW + q;
-            if (ww < W && hh < H) {
-                const long yp = ((b * H + hh) * (long)W + ww) * C;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int c = 4 * (cl + v * LPP);
-                    f32x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][q][e] * rstd;
-                    if (ln_w) {
-                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
-                    }
-                    if (shift) {
-                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
-                    }
-                    st4<BF>(y, yp + c, o4);
-                }
-            }
-        }
-    }
-}
-
-// Third-generation tiled form ("t3"), built from what the counters said about the two before it: per CU the operator needs ~28 us of
-// packed FMAs, ~33 us of LDS fragment reads, ~20-36 us of halo staging and 30-60 us of HBM time on the stride-4 maps -- the earlier
-// kernels run these one after the other (dwconv_ln_tile_kernel: waves parked 40 % + stalled 23 % of their cycles), t2 overlapped
-// them across workgroups but staged 3.4 halo pixels per output pixel.  Here ONE 512-thread workgroup per CU overlaps them itself:
-//   * a pixel group is 8 lanes (chunk = 32 channels = 128 B per pixel), so a halo tile of a chunk is small enough to DOUBLE-BUFFER
-//     in LDS next to ALL the weights (k = 7, C = 192: 2 x 61 KB + 37 KB): chunk q+1 is written into the other buffer in the middle of
-//     chunk q's taps and its global loads were issued a whole chunk earlier -- one barrier per chunk, no exposed staging phase;
-//   * 16 x 16 pixel tiles for C <= 192 (4 pixels per lane group: 1.9 halo pixels staged per output pixel), 8 x 16 tiles with 2 pixels
-//     per group for C = 256..512 (the accumulators of all C channels of a pixel must stay in registers for the LayerNorm);
-//   * packed FMAs (v_pk_fma_f32): each component is an fmaf, same bits, half the VALU issue slots.
-// The LayerNorm sums reproduce the association of dwconv_ln_kernel's <.., LPP = RL, ..> instance for this C: lane l of the 8 holds
-// the 4-channel chunks l + 8 j; reference lane c = (l + 8 j) mod RL adds its chunks in ascending order, then the reference's xor
-// butterfly: its steps >= 8 combine partial sums that live in ONE lane here, the steps 4, 2, 1 cross the 8 lanes.  Same bits as every
-// other form of this operator (tests/test_gpu_kernels.py), so the launcher may choose by map size.
-template <bool BF> struct DwStage { typedef f32x4 type; };
-template <> struct DwStage<true> { typedef u32x2 type; };
-
-template <int KS, int NV8, int RL, int TW, bool BF>
-__global__ __launch_bounds__(512, 1) void dwconv_ln_t3_kernel(const void* __restrict__ x, const float* __restrict__ wt,
-                                                              const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                              const float* __restrict__ ln_b, const float* __restrict__ shift,
-                                                              const float* __restrict__ scale1p, void* __restrict__ y,
-                                                              int B, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
-    constexpr int LPP = 8, TBW = 16, GX = TBW / TW, GY = 64 / GX, TBH = GY, PGB = 64;
-    constexpr int C = 32 * NV8, NG = RL / 8;                         // NG reference lanes (c = l + 8 g) share one lane here
-    constexpr int P = (KS - 1) / 2, LW = TBW + KS - 1, LH = TBH + KS - 1, NPIX = LW * LH, KK = KS * KS;
-    constexpr int NF = (NPIX + PGB - 1) / PGB;                       // staged pixels per thread per chunk
-    static_assert(NV8 % NG == 0 && NV8 % 2 == 0, "chunks per reference lane / buffer parity");
-    typedef typename DwStage<BF>::type stage_t;
-    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    f32x4* tile0 = (f32x4*)dw_lds;                                  // [2][NPIX][8]
-    f32x4* wl = tile0 + 2 * NPIX * LPP;                             // [NV8][KK][8]
-    const int tid = threadIdx.x, cl = tid % LPP, pg = tid / LPP;
-    const int gy = pg / GX, gx = pg % GX;
-    const int nb = gridDim.x, bq = nb / 8, br = nb % 8, xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
-    const int bid = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + loc;
-    const int per = n_tiles / nb, rem = n_tiles % nb;
-    const int t_begin = bid * per + (bid < rem ? bid : rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
-    if (t_begin >= t_end) return;
-
-    for (int e = tid; e < NV8 * KK * LPP; e += 512) {                // weights: wl[(v*KK + tap)*8 + lane] = wt[tap*C + 4*(lane + 8 v)]
-        const int lane = e % LPP, tap = (e / LPP) % KK, v = e / (LPP * KK);
-        wl[e] = *(const f32x4*)(wt + (long)tap * C + 4 * (lane + v * LPP));
-    }
-    // LDS pixel slot: p ^ ((p >> 2) & 1).  The four pixel groups a 16-lane ds_read_b128 service group spans sit 4 pixels apart
-    // (same parity => same 32-bank half with 128-B pixels: 2-way conflicts); swapping the pixels of every other aligned quad in pairs
-    // alternates the half from group to group.
-    auto slot = [](int p) { return p ^ ((p >> 2) & 1); };
-    stage_t st[NF];
-    unsigned inmask = 0;
-    auto prefetch = [&](int t, int v) {                              // global -> registers, branch-free (clamped address + mask)
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const long xb = b * (long)H * W * C + 4 * (cl + v * LPP);
-        const int h0 = ty * TBH - P, w0 = tx * TBW - P;
-        inmask = 0;
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int pix = pg + PGB * n, ly = pix / LW, lx = pix - ly * LW;
-            const int hh = h0 + ly, ww = w0 + lx;
-            const bool in = pix < NPIX && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            inmask |= (in ? 1u : 0u) << n;
-            const long off = xb + (in ? ((long)hh * W + ww) * C : 0);
-            if (BF) st[n] = *(const stage_t*)((const unsigned short*)x + off);
-            else st[n] = *(const stage_t*)((const float*)x + off);
-        }
-    };
-    auto commit = [&](f32x4* tile) {                                 // registers -> LDS (other buffer)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            if (pg + PGB * n < NPIX) {
-                f32x4 v4;
-                if constexpr (BF) {
-                    v4 = (f32x4){__uint_as_float(st[n][0] << 16), __uint_as_float(st[n][0] & 0xffff0000u), __uint_as_float(st[n][1] << 16),
-                                 __uint_as_float(st[n][1] & 0xffff0000u)};
-                } else {
-                    v4 = st[n];
-                }
-                tile[slot(pg + PGB * n) * LPP + cl] = ((inmask >> n) & 1u) ? v4 : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-
-    prefetch(t_begin, 0);
-    commit(tile0);
-    prefetch(t_begin, 1);                                            // NV8 >= 2
-    __syncthreads();                                                 // weights + first chunk visible
-    for (int t = t_begin; t < t_end; ++t) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
-        const long b = t / (tiles_x * tiles_y);
-        const int h0 = ty * TBH, w0 = tx * TBW;
-        f32x4 acc[NV8][TW];
-#pragma unroll
-        for (int v = 0; v < NV8; ++v) {
-            const f32x4* tile = tile0 + (v & 1) * NPIX * LPP;        // NV8 is even: chunk parity == buffer parity for every tile
-            f32x4* other = tile0 + ((v & 1) ^ 1) * NPIX * LPP;
-            const bool has_next = (v + 1 < NV8) || (t + 1 < t_end);
-            const f32x4 bv = *(const f32x4*)(bias + 4 * (cl + v * LPP));
-#pragma unroll
-            for (int q = 0; q < TW; ++q) acc[v][q] = bv;
-            // (a two-row software pipeline of this loop -- row i + 1's 17 fragment reads in flight behind row i's FMAs -- needs ~270
-            //  registers with the staging set and spilled: 141 -> 207 us; measured and dropped)
-#pragma unroll 1
-            for (int i = 0; i < KS; ++i) {
-                const int p0 = (gy + i) * LW + gx * TW;
-                const f32x4* wrow = wl + (v * KK + i * KS) * LPP + cl;
-                f32x4 xr[TW + KS - 1];
-#pragma unroll
-                for (int q = 0; q < TW + KS - 1; ++q) xr[q] = tile[slot(p0 + q) * LPP + cl];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const f32x4 wv = wrow[j * LPP];
-#pragma unroll
-                    for (int q = 0; q < TW; ++q) acc[v][q] = __builtin_elementwise_fma(xr[q + j], wv, acc[v][q]);
-                }
-                if (i == KS / 2 && has_next) {
-                    // the next chunk (in flight since the previous step) goes into the other buffer, whose last readers passed the
-                    // barrier that ended the previous step; then the chunk after it is requested
-                    commit(other);
-                    int t2 = t, v2 = v + 2;
-                    if (v2 >= NV8) { t2 = t + 1; v2 -= NV8; }
-                    if (t2 < t_end) prefetch(t2, v2);
-                }
-            }
-            if (v + 1 < NV8) __syncthreads();
-        }
-        const float inv_c = 1.0f / (float)C;
-        const int hh = h0 + gy;
-#pragma unroll
-        for (int q = 0; q < TW; ++q) {
-            float pgs[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float s = 0.f;
-#pragma unroll
-                for (int v = g; v < NV8; v += NG) s += (acc[v][q][0] + acc[v][q][1]) + (acc[v][q][2] + acc[v][q][3]);
-                pgs[g] = s;
-            }
-            float s;
-            if (NG == 4) s = (pgs[0] + pgs[2]) + (pgs[1] + pgs[3]);   // the reference's lane ^ 16 step, then lane ^ 8
-            else s = pgs[0] + pgs[1];                                 // lane ^ 8
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            const float mean = s * inv_c;
-            float qgs[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float sq = 0.f;
-#pragma unroll
-                for (int v = g; v < NV8; v += NG) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = acc[v][q][e] - mean;
-                        acc[v][q][e] = dlt;
-                        sq = fmaf(dlt, dlt, sq);
-                    }
-                }
-                qgs[g] = sq;
-            }
-            float sq;
-            if (NG == 4) sq = (qgs[0] + qgs[2]) + (qgs[1] + qgs[3]);
-            else sq = qgs[0] + qgs[1];
-#pragma unroll
-            for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            const float rstd = 1.0f / sqrtf(sq * inv_c + 1e-6f);
-            const int ww = w0 + gx * TW + q;
-            if (ww < W && hh < H) {
-                const long yp = ((b * H + hh) * (long)W + ww) * C;
-#pragma unroll
-                for (int v = 0; v < NV8; ++v) {
-                    const int c = 4 * (cl + v * LPP);
-                    f32x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = acc[v][q][e] * rstd;
-                    if (ln_w) {
-                        const f32x4 lw = *(const f32x4*)(ln_w + c), lb = *(const f32x4*)(ln_b + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * lw[e] + lb[e];
-                    }
-                    if (shift) {
-                        const f32x4 sc = *(const f32x4*)(scale1p + c), sh = *(const f32x4*)(shift + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = o4[e] * sc[e] + sh[e];
-                    }
-                    st4<BF>(y, yp + c, o4);
-                }
-            }
-        }
-        __syncthreads();                                             // the last chunk's readers are done before its buffer is rewritten
-    }
-}
-
-int g_dw_t3 = -1;      // tuning hook (LVAE_DW_T3): 0 = never, 1 = whenever an instance exists, -1 = heuristic
-
-template <int KS, int NV8, int RL, int TW, bool BF>
-int launch_dwln_t3(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
-                   const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
-    constexpr int TBH = 64 / (16 / TW), NPIX = (16 + KS - 1) * (TBH + KS - 1), LDS = (2 * NPIX * 8 + NV8 * KS * KS * 8) * 16;
-    static_assert(LDS <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv_ln_t3_kernel<KS, NV8, RL, TW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + TBH - 1) / TBH;
-    const long n_tiles = (long)B * tiles_x * tiles_y;
-    const int grid = (int)(n_tiles < 256 ? n_tiles : 256);
-    hipLaunchKernelGGL((dwconv_ln_t3_kernel<KS, NV8, RL, TW, BF>), dim3(grid), dim3(512), LDS, st, x, wt, bias, ln_w, ln_b, shift, scale1p, y,
-                       B, H, W, tiles_x, tiles_y, (int)n_tiles);
-    return (int)hipGetLastError();
-}
-
-// t3 is taken when the map has at least one tile per CU (below that the register sliding-window kernel's finer granularity wins)
-template <int KS, bool BF>
-int try_dwln_t3(int C, const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
-                const float* scale1p, void* y, int B, int H, int W, hipStream_t st, int* rc) {
-    // bf16 maps only: on fp32 maps it ties dwconv_ln_tile_kernel (B = 8, 128x192, C = 192: 137 vs 134 us) and loses to the sliding-window
-    // kernel at C >= 256 (106 vs 82 us).  What all forms share is the tap loop: per tap ~0.55 us of FMA issue + ~0.67 us of LDS
-    // fragment reads that do not overlap at two waves per SIMD (measured: t = 57 + 1.45 k^2 us for k = 1, 3, 5, 7), and the registers
-    // that a two-row software pipeline would need are taken by the accumulators of all C channels (LayerNorm needs them together).
-    if constexpr (KS >= 3 && BF) {
-        if (g_dw_t3 == 0) return 0;
-        const int tbh = C <= 192 ? 16 : 8;
-        const long n_tiles = (long)B * ((W + 15) / 16) * ((H + tbh - 1) / tbh);
-        if (g_dw_t3 < 0 && n_tiles < 256) return 0;
-        switch (C) {
-            case 128: *rc = launch_dwln_t3<KS, 4, 16, 4, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 192: *rc = launch_dwln_t3<KS, 6, 16, 4, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 256: *rc = launch_dwln_t3<KS, 8, 32, 2, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 384: *rc = launch_dwln_t3<KS, 12, 32, 2, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 512:
-                if constexpr (KS <= 5) { *rc = launch_dwln_t3<KS, 16, 32, 2, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1; }
-                return 0;
-        }
-    }
-    return 0;
-}
-
-int g_dw_t2 = -1;      // tuning hook (LVAE_DW_T2): 0 = never, 1 = whenever an instance exists, -1 = heuristic
-
-template <int KS, int NV, int RL, bool BF>
-int launch_dwln_t2(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
-                   const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
-    constexpr int NPIX = (16 + KS - 1) * (4 + KS - 1), LDS = (NPIX + KS * KS) * 256;
-    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv_ln_t2_kernel<KS, NV, RL, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + 3) / 4;
-    const long n_tiles = (long)B * tiles_x * tiles_y;
-    const int per_cu = (160 * 1024) / LDS < 4 ? (160 * 1024) / LDS : 4;
-    const long cap = 256L * per_cu;
-    const int grid = (int)(n_tiles < cap ? n_tiles : cap);
-    hipLaunchKernelGGL((dwconv_ln_t2_kernel<KS, NV, RL, BF>), dim3(grid), dim3(256), LDS, st, x, wt, bias, ln_w, ln_b, shift, scale1p, y,
-                       B, H, W, tiles_x, tiles_y, (int)n_tiles);
-    return (int)hipGetLastError();
-}
-
-// t2 is taken when the map has at least ~1.5 tiles per CU (below that the register sliding-window kernel's finer granularity wins)
-template <int KS, bool BF>
-int try_dwln_t2(int C, const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
-                const float* scale1p, void* y, int B, int H, int W, hipStream_t st, int* rc) {
-    if constexpr (KS >= 3) {
-        const long n_tiles = (long)B * ((W + 15) / 16) * ((H + 3) / 4);
-        // fp32 maps: measured no faster than dwconv_ln_tile_kernel / the sliding-window kernel (B = 8, 128x192, C = 192: 172 vs 134 us --
-        // its 4 x 16 tiles stage 3.4 halo pixels per output pixel against 2.4 for the 8 x 16 tiles), so it is taken for bf16 maps only,
-        // where it replaces the 8-byte-per-lane sliding-window loads (257 -> 140 us); LVAE_DW_T2=1 forces it for experiments
-        if (g_dw_t2 == 0 || (g_dw_t2 < 0 && (!BF || n_tiles < 384))) return 0;
-        switch (C) {
-            case 128: *rc = launch_dwln_t2<KS, 2, 16, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 192: *rc = launch_dwln_t2<KS, 3, 16, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 256: *rc = launch_dwln_t2<KS, 4, 32, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-            case 384: *rc = launch_dwln_t2<KS, 6, 32, BF>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st); return 1;
-        }
-    }
-    return 0;
-}
-
-int g_dw_tile = -1;    // tuning hook (LVAE_DW_TILE): 0 = never, 1 = whenever an instance exists, -1 = heuristic
-
-template <int KS, int VPL>
-int launch_dwln_tile(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
-                     const float* shift, const float* scale1p, float* y, int B, int H, int W, hipStream_t st) {
-    constexpr int NPIX = (16 + KS - 1) * (8 + KS - 1), LDS = (NPIX + VPL * KS * KS) * 256;
-    static_assert(LDS <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv_ln_tile_kernel<KS, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + 7) / 8;
-    const long n_tiles = (long)B * tiles_x * tiles_y;
-    const int grid = n_tiles < 256 ? (int)n_tiles : 256;
-    hipLaunchKernelGGL((dwconv_ln_tile_kernel<KS, VPL>), dim3(grid), dim3(512), LDS, st, x, wt, bias, ln_w, ln_b, shift, scale1p, y,
-                       B, H, W, tiles_x, tiles_y, (int)n_tiles);
-    return (int)hipGetLastError();
-}
-
 int g_dw_th = 0;       // tuning hook (LVAE_DW_TH): 1 or 2 output rows per group; 0 = heuristic
 
 template <int KS, int VPL, int LPP, int TH, bool BF = false>
@@ -824,10 +202,6 @@ int launch_dwln(const float* x, const float* wt, const float* bias, const float*
     // slower on the C >= 256 layers, where 200+ VGPRs halve the occupancy.  Same accumulation order => same bits either way.
     const long px = (long)B * H * W;
     constexpr int C = 4 * VPL * LPP;
-    if constexpr (KS >= 5 && LPP == 16 && VPL <= 3) {
-        if (g_dw_tile == 1 || (g_dw_tile < 0 && px >= 90000 && H >= 16 && W >= 32))      // >= ~3 tiles per CU; measured equal at 1.5
-            return launch_dwln_tile<KS, VPL>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
-    }
     int th = g_dw_th ? g_dw_th : ((KS == 7 && C <= 192 && VPL <= 3 && px >= 100000) ? 2 : 1);
     if (KS == 1 || VPL > 4) th = 1;          // VPL = 9 (C = 144, 288) has no registers for a second row
     if (th == 2) return launch_dwln_th<KS, VPL, LPP, (KS == 1 ? 1 : 2)>(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -849,7 +223,7 @@ int dispatch_dwln_c(int C, const float* x, const float* wt, const float* bias, c
     return -22;
 }
 
-// bf16-storage form (reduced-precision mode): the register sliding-window kernel, one output row per group
+// bf16-storage form of the sliding-window kernel (reached for the two-affine case only), one output row per group
 template <int KS>
 int dispatch_dwln_bf16(int C, const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                        const float* shift, const float* scale1p, void* y, int B, int H, int W, hipStream_t st) {
@@ -1139,7 +513,8 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
 
 }  // namespace
 
-// dwconv_cl.hip: the channel-per-lane form (rolling register window, weights in registers); takes the problem by (C, k) alone
+// dwconv_cl.hip: the channel-per-lane form (weights in registers, LDS-DMA row buffers) takes the problem by (C, k) alone; what follows
+// here is the sliding-window kernel for the other channel counts (qres17m: C = 144 / 288) and the two-affine case
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
                      const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc);
 
@@ -1155,28 +530,9 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
     static bool env_read = false;
     if (!env_read) {
         const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e);
-        e = getenv("LVAE_DW_TILE"); if (e) g_dw_tile = atoi(e);
         env_read = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    {
-        const char* e = nullptr;
-        static bool t2_read = false;
-        if (!t2_read) { e = getenv("LVAE_DW_T2"); if (e) g_dw_t2 = atoi(e); t2_read = true; }
-        int rc = 0;
-        static bool t3_read = false;
-        if (!t3_read) { const char* e3 = getenv("LVAE_DW_T3"); if (e3) g_dw_t3 = atoi(e3); t3_read = true; }
-        if (g_dw_tile != 1 && g_dw_th == 0 && g_dw_t2 != 1) {
-            if (k == 3 && try_dwln_t3<3, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 5 && try_dwln_t3<5, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 7 && try_dwln_t3<7, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-        }
-        if (g_dw_tile != 1 && g_dw_th == 0) {
-            if (k == 3 && try_dwln_t2<3, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 5 && try_dwln_t2<5, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 7 && try_dwln_t2<7, false>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-        }
-    }
     switch (k) {
         case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
         case 3: return dispatch_dwln_c<3>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -1213,21 +569,6 @@ extern "C" int lvae_dwconv_ln_bf16(const void* x, const float* wt, const float* 
     {
         int rc = 0;
         if (lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 1, st, &rc)) return rc;
-    }
-    {
-        static bool t2_read = false;
-        if (!t2_read) { const char* e = getenv("LVAE_DW_T2"); if (e) g_dw_t2 = atoi(e); t2_read = true; }
-        int rc = 0;
-        static bool t3_read = false;
-        if (!t3_read) { const char* e3 = getenv("LVAE_DW_T3"); if (e3) g_dw_t3 = atoi(e3); t3_read = true; }
-        if (g_dw_t2 != 1) {
-            if (k == 3 && try_dwln_t3<3, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 5 && try_dwln_t3<5, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-            if (k == 7 && try_dwln_t3<7, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-        }
-        if (k == 3 && try_dwln_t2<3, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-        if (k == 5 && try_dwln_t2<5, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
-        if (k == 7 && try_dwln_t2<7, true>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st, &rc)) return rc;
     }
     switch (k) {
         case 1: return dispatch_dwln_bf16<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);

@@ -504,8 +504,8 @@ def test_gemm_split_k_in_kernel_reduction_under_load():
 @pytest.mark.parametrize('C,k,H,W,B', [(192, 7, 96, 160, 7), (128, 7, 61, 99, 18), (192, 5, 70, 130, 11), (128, 5, 64, 128, 12),
                                        (128, 7, 17, 33, 170)])
 def test_dwconv_ln_large_map_variants_same_bits(L, C, k, H, W, B):
-    """Above 90 000 pixels per launch the k >= 5, C <= 192 layers run the LDS-tiled persistent kernel: a batch over the threshold
-    must give, image by image, the bits of single-image calls (register sliding-window kernel) -- ragged sizes included."""
+    """The depthwise+LN launcher picks its tile height (rows per workgroup) from the map size and the batch: a large batch must give,
+    image by image, the bits of single-image calls -- ragged sizes included."""
     g = torch.Generator().manual_seed(C + k + H + W)
     x1 = torch.randn(3, H, W, C, generator=g).cuda()
     x = x1.repeat((B + 2) // 3, 1, 1, 1)[:B].contiguous()
