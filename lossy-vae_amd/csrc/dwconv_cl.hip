@@ -66,8 +66,8 @@ __device__ __forceinline__ unsigned f2bf_rne(float x) {
 // **a packed op whose LOW lane selects the HIGH dword of an operand (`op_sel` = 1) returned occasional wrong low-lane results on MI355X
 // whenever MFMA kernels shared the CUs.**  With the weight pair as src1 (`op_sel:[0,1,0]`) 20-30 % of the launches beside split-K GEMMs
 // on a second stream had a few pixels off (always even columns = low lanes; run-to-run different bitstreams in the bf16x3 model only,
-// whose GEMMs are MFMA-dense enough), 0 of 400 alone; as src0 (`op_sel:[1,0,0]`) 0 of 1600 on four boxes but 359 of 400 on a fifth.
-// hipcc never emits that form for packed f32 arithmetic; its `v_pk_mov_b32 ... op_sel:[1,0]` for a pair assembled from two odd halves
+// whose GEMMs are MFMA-dense enough), 0 of 400 alone; as src0 (`op_sel:[1,0,0]`) 0 of 1600 -- not trusted either: hipcc never emits
+// that selection for packed f32 arithmetic, and the scalar form costs 2 %; its `v_pk_mov_b32 ... op_sel:[1,0]` for a pair assembled from two odd halves
 // is the same selection, so those pairs are assembled with two v_mov_b32 here.  tests/test_gpu_kernels.py::test_dwconv_ln_beside_gemms.
 __device__ __forceinline__ void pk_fma_wlo(f32x2& a, f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(x), "v"(w));

@@ -6,6 +6,7 @@ to ~1e-6 relative of sum|a*b| -- asserted as 2e-5 abs on O(1) data (the north-st
 import ctypes
 
 import numpy as np
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -238,18 +239,28 @@ def test_dwconv_ln_beside_gemms(L):
         o = torch.empty(c['M'], c['N'], device='cuda'); gm(c, o, cur); torch.cuda.synchronize(); gm_ref.append(o)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     bad_dw = bad_gm = 0
+    notes = []
     for rep in range(40):
         outs_dw, outs_gm = [], []
         for i in range(10):
             di, gi = (i + rep) % len(dw_cases), (i + 2 * rep) % len(gm_cases)
-            y = torch.full_like(dw_cases[di]['x'], float('nan'))
+            with torch.cuda.stream(s1):          # the NaN fill must be ordered before the kernel: same stream
+                y = torch.full_like(dw_cases[di]['x'], float('nan'))
             dw(dw_cases[di], y, s1); outs_dw.append((y, dw_ref[di]))
             o = torch.empty(gm_cases[gi]['M'], gm_cases[gi]['N'], device='cuda')
             gm(gm_cases[gi], o, s2); outs_gm.append((o, gm_ref[gi]))
         torch.cuda.synchronize()
-        bad_dw += sum(0 if torch.equal(a, b) else 1 for a, b in outs_dw)
         bad_gm += sum(0 if torch.equal(a, b) else 1 for a, b in outs_gm)
-    assert (bad_dw, bad_gm) == (0, 0)
+        for a, b in outs_dw:
+            if not torch.equal(a, b):
+                bad_dw += 1
+                if len(notes) < 6:          # which pixels, and do two fresh solo runs agree with the reference?
+                    px = (a != b).any(dim=3).nonzero()
+                    ci = next(i for i, r in enumerate(dw_ref) if r is b)
+                    y1 = torch.empty_like(b); dw(dw_cases[ci], y1, cur); torch.cuda.synchronize()
+                    notes.append(dict(shape=tuple(a.shape), n_px=len(px), first=px[:4].tolist(), max=float((a - b).abs().max()),
+                                      solo_again_equals_ref=bool(torch.equal(y1, b)), solo_again_equals_this=bool(torch.equal(y1, a))))
+    assert (bad_dw, bad_gm) == (0, 0), notes
 
 
 def test_stem(L):

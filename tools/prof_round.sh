@@ -28,4 +28,11 @@ python $R/bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel
 python $R/bench.py --batch 4 --height 1216 --width 1216 --steps 5 --warmup 2 --no-cpu-baseline --fp32-steps 0 > $O/bench_b4_1216.json 2>/dev/null
 python $R/bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32_mode.json 2>/dev/null
 python $R/bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_mode.json 2>/dev/null
+# 7. depthwise+LN kernel: timings on the model's shapes, PMC passes of the largest layer (B = 8, 128x192, C = 192, k = 7)
+python $R/tools/dw_bench.py 2>&1 | grep -v amdgpu > $O/dw_bench.txt
+DW_ONLY=3 bash $R/tools/pmc_dw.sh > $O/pmc_dwconv_ln_cl.txt 2>&1
+# 8. per-op tables (single stream, HIP events around every launch)
+python $R/tools/op_times.py 8 2>&1 | grep -v amdgpu > $O/op_times_b8.txt
+python $R/tools/op_times.py 1 2>&1 | grep -v amdgpu > $O/op_times_b1.txt
+LVAE_PRECISION=fp8 python $R/tools/op_times.py 8 2>&1 | grep -v amdgpu > $O/op_times_fp8.txt
 ls -la $O

@@ -41,13 +41,17 @@ shown = 0
 for rep in range(40):
     outs_dw, outs_gm = [], []
     for i in range(10):
-        c = dw_cases[(i + rep) % len(dw_cases)]; y = torch.full_like(c['x'], float('nan'))
+        c = dw_cases[(i + rep) % len(dw_cases)]
+        with torch.cuda.stream(s1):          # the fill must be ordered before the kernel
+            y = torch.full_like(c['x'], float('nan'))
         dw(c, y, s1); outs_dw.append((y, dw_ref[(i + rep) % len(dw_cases)]))
         if mode == 'both':
             c2 = gm_cases[(i + 2 * rep) % len(gm_cases)]; o = torch.empty(c2['M'], c2['N'], device='cuda')
             gm(c2, o, s2); outs_gm.append((o, gm_ref[(i + 2 * rep) % len(gm_cases)]))
         elif mode == 'dwdw':
-            c2 = dw_cases[(i + 2 * rep + 1) % len(dw_cases)]; y2 = torch.full_like(c2['x'], float('nan'))
+            c2 = dw_cases[(i + 2 * rep + 1) % len(dw_cases)]
+            with torch.cuda.stream(s2):
+                y2 = torch.full_like(c2['x'], float('nan'))
             dw(c2, y2, s2); outs_dw.append((y2, dw_ref[(i + 2 * rep + 1) % len(dw_cases)]))
     torch.cuda.synchronize()
     bad_dw += sum(0 if torch.equal(a, b) else 1 for a, b in outs_dw); bad_gm += sum(0 if torch.equal(a, b) else 1 for a, b in outs_gm)
