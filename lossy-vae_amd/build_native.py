@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lvae', '_native')
 OUT = os.path.join(OUT_DIR, 'liblvae_hip.so')
-SOURCES = ['gemm_f32.hip', 'gemm_x3v2.hip', 'gemm_lp.hip', 'pointwise.hip', 'dwconv_cl.hip', 'rans_host.cpp']
-HEADERS = ['gemm_common.h', 'device_math.h']
+SOURCES = ['gemm_f32.hip', 'gemm_x3v2.hip', 'gemm_lp.hip', 'pointwise.hip', 'dwconv_cl.hip', 'dwconv_cl_bf16.hip', 'rans_host.cpp']
+HEADERS = ['gemm_common.h', 'device_math.h', 'dwconv_cl.hip']       # dwconv_cl.hip is also #included by dwconv_cl_bf16.hip
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lvae_hip.h')
 
 

@@ -20,7 +20,7 @@
 //     steps per lane; the C/64 waves exchange their per-pixel partial sums through LDS (two workgroup barriers per output row).
 // Zero padding comes from the buffer unit: a row's resource descriptor covers exactly that image row (num_records = 0 for rows outside
 // the image), so columns left / right of the image and rows above / below read as hardware zeros without masks on the data path.
-// TH (8, 4, 2 or 1 output rows per workgroup; k - 1 halo rows are re-read per tile, from L2) only changes the parallelism, never an
+// TH (8, 4 or 1 output rows per workgroup; k - 1 halo rows are re-read per tile, from L2) only changes the parallelism, never an
 // output bit, so the launcher picks it from the map size.
 //
 // Arithmetic: the conv chain is the earlier kernels' (same bits); the LayerNorm uses THIS kernel's association (per wave: mean and
@@ -323,8 +323,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
     }
 }
 
-int g_dw_cl = -1;          // tuning hook LVAE_DW_CL: 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 2 / 4 / 8) = force, -1 = heuristic
-bool g_dw_cl_read = false;
+}  // namespace
+// tuning hook LVAE_DW_CL: 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 4 / 8) = force, -1 = heuristic
+#ifdef LVAE_CL_BF16_TU
+extern int g_dw_cl;
+#else
+int g_dw_cl = -1;
+#endif
+namespace {
 
 template <int KS, int NW, int TH, bool BF>
 int launch_cl_th(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
@@ -349,6 +355,7 @@ int launch_cl(const void* x, const float* wt, const float* bias, const float* aw
     double best_t = 1e300;
     for (int th = 1; th <= 8; th *= 2) {
         if (KS == 1 && th > 1) break;                                  // k = 1: nothing is shared between rows
+        if (th == 2) continue;                                         // not instantiated (compile time; 1 / 4 / 8 cover the map sizes)
         const int by_waves = (KS >= 5 && th == 8 ? 12 : 16) / NW, by_lds = (160 * 1024) / LDSB;
         const long slots = 256L * (by_waves < by_lds ? by_waves : by_lds);
         const int n_ty = (H + th - 1) / th;
@@ -365,8 +372,7 @@ int launch_cl(const void* x, const float* wt, const float* bias, const float* aw
     if (g_dw_cl > 0 && (KS > 1 || g_dw_cl % 10 == 1)) { TH = g_dw_cl % 10; tpw = g_dw_cl / 10 > 0 ? g_dw_cl / 10 : 1; }   // hook: 10 * tpw + TH
     if constexpr (KS > 1) {
         if (TH == 8) return launch_cl_th<KS, NW, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
-        if (TH == 4) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
-        if (TH == 2) return launch_cl_th<KS, NW, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH >= 2) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
     }
     return launch_cl_th<KS, NW, 1, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
 }
@@ -386,28 +392,42 @@ int launch_cl_c(int C, const void* x, const float* wt, const float* bias, const 
 
 }  // namespace
 
+// This source is compiled twice (build_native.py): as is (fp32 maps + the entry point) and, through dwconv_cl_bf16.hip, with
+// LVAE_CL_BF16_TU (the bf16-map instances) -- two translation units compile in parallel, the 130 instances take minutes otherwise.
+#ifdef LVAE_CL_BF16_TU
+int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                             int B, int H, int W, hipStream_t st) {
+    switch (k) {
+        case 1: return launch_cl_c<1, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 3: return launch_cl_c<3, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 5: return launch_cl_c<5, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 7: return launch_cl_c<7, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+    }
+    return -22;
+}
+#else
+int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                             int B, int H, int W, hipStream_t st);
+
 // Entry point for pointwise.hip's dispatchers.  Returns 1 when this kernel takes the problem (*rc = launch status), 0 otherwise.
 // Taken for C in {128, 192, 256, 384, 512}, k in {1, 3, 5, 7} and at most ONE per-channel affine after the normalisation -- a rule
 // in (C, k, which pointers are given) only, because this kernel's LayerNorm association differs from the other forms'.
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
                      const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc) {
-    if (!g_dw_cl_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); g_dw_cl_read = true; }
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); env_read = true; }
     if (g_dw_cl == 0) return 0;
     if (ln_w && shift) return 0;
     if (!(C == 128 || C == 192 || C == 256 || C == 384 || C == 512) || !(k == 1 || k == 3 || k == 5 || k == 7)) return 0;
     const float* aw = ln_w ? ln_w : scale1p;
     const float* ab = ln_w ? ln_b : shift;
-#define LVAE_CL_CASE(KS)                                                                                          \
-    case KS:                                                                                                      \
-        *rc = bf16 ? launch_cl_c<KS, true>(C, x, wt, bias, aw, ab, y, B, H, W, st)                                 \
-                   : launch_cl_c<KS, false>(C, x, wt, bias, aw, ab, y, B, H, W, st);                               \
-        return 1;
+    if (bf16) { *rc = lvae_dwln_cl_launch_bf16(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
     switch (k) {
-        LVAE_CL_CASE(1)
-        LVAE_CL_CASE(3)
-        LVAE_CL_CASE(5)
-        LVAE_CL_CASE(7)
+        case 1: *rc = launch_cl_c<1, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;
+        case 3: *rc = launch_cl_c<3, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;
+        case 5: *rc = launch_cl_c<5, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;
+        case 7: *rc = launch_cl_c<7, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;
     }
-#undef LVAE_CL_CASE
     return 0;
 }
+#endif
