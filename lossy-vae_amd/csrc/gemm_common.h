@@ -188,17 +188,10 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
     }
 }
 
-// Split-K tail: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias) for the BM x BN tile at (m0, n0): 4 columns per
-// thread, 16-B accesses.  Shared by the in-kernel reduction (the tile's last-arriving slice workgroup) and by the stand-alone reduce
-// kernel (d.cnt == NULL): same operations in the same order, hence the same bits.
-__device__ __forceinline__ void splitk_reduce_chunk(const lvae_gemm_desc& d, int S, long m, int c) {
-    const long plane = (long)d.M * d.N;
-    const float* w = d.ws + m * d.N + c;
-    f32x4 v = *(const f32x4*)w;
-    for (int s = 1; s < S; ++s) {
-        const f32x4 p = *(const f32x4*)(w + s * plane);
-        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
-    }
+// Split-K tail: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias) for 16-B chunks of the output.  Shared by the in-kernel
+// reduction (the tile's last-arriving slice workgroup) and by the stand-alone reduce kernel (d.cnt == NULL): same operations in the
+// same order, hence the same bits.
+__device__ __forceinline__ void splitk_epilogue_store(const lvae_gemm_desc& d, long m, int c, f32x4 v) {
     if (d.bias) { const f32x4 b = *(const f32x4*)(d.bias + c); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     if (d.epi == LVAE_EPI_BIAS_GELU) {
         float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
@@ -212,6 +205,45 @@ __device__ __forceinline__ void splitk_reduce_chunk(const lvae_gemm_desc& d, int
         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
     }
     *(f32x4*)(d.out + m * d.ldo + c) = v;
+}
+__device__ __forceinline__ void splitk_reduce_chunk(const lvae_gemm_desc& d, int S, long m, int c) {
+    const long plane = (long)d.M * d.N;
+    const float* w = d.ws + m * d.N + c;
+    f32x4 v = *(const f32x4*)w;
+    for (int s = 1; s < S; ++s) {
+        const f32x4 p = *(const f32x4*)(w + s * plane);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    splitk_epilogue_store(d, m, c, v);
+}
+// U chunks per thread at once (chunk e0 + u * stride of the rows x c4n chunk grid of the tile at (m0, n0)): the U loads of a slab are in
+// flight together.  One workgroup reduces a whole tile here, alone, from memory: with one chunk at a time it spent S dependent memory
+// round trips per 4 KB (a 128 x 192 tile with S = 2: ~50 us; the stand-alone reduce kernel spreads the same bytes over the chip).
+template <int U>
+__device__ __forceinline__ void splitk_reduce_chunks(const lvae_gemm_desc& d, int S, int m0, int n0, int c4n, int e0, int stride, int total) {
+    const long plane = (long)d.M * d.N;
+    const float* w[U];
+    f32x4 v[U];
+    long m[U];
+    int c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * stride, ee = e < total ? e : e0;
+        const int r = ee / c4n;
+        m[u] = m0 + r; c[u] = n0 + 4 * (ee - r * c4n);
+        w[u] = d.ws + m[u] * d.N + c[u];
+        v[u] = *(const f32x4*)w[u];
+    }
+    for (int s = 1; s < S; ++s) {
+        f32x4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = *(const f32x4*)(w[u] + s * plane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u][0] += p[u][0]; v[u][1] += p[u][1]; v[u][2] += p[u][2]; v[u][3] += p[u][3]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (e0 + u * stride < total) splitk_epilogue_store(d, m[u], c[u], v[u]);
 }
 
 // Every GEMM kernel ends here.  gridDim.y = number of K slices: with split-K the raw partial sums of slice blockIdx.y go to its
@@ -255,10 +287,7 @@ __device__ __forceinline__ void gemm_finish(const lvae_gemm_desc& d, f32x16 (&ac
             const int rows = (d.M - m0) < C::BM ? (d.M - m0) : C::BM;
             const int cols = (d.N - n0) < C::BN ? (d.N - n0) : C::BN;       // N % 4 == 0 (checked on the host)
             const int c4n = cols >> 2;
-            for (int e = threadIdx.x; e < rows * c4n; e += C::NT) {
-                const int r = e / c4n, c4 = e - r * c4n;
-                splitk_reduce_chunk(d, S, (long)(m0 + r), n0 + 4 * c4);
-            }
+            for (int e0 = threadIdx.x; e0 < rows * c4n; e0 += C::NT * 8) splitk_reduce_chunks<8>(d, S, m0, n0, c4n, e0, C::NT, rows * c4n);
         }
     }
 }
