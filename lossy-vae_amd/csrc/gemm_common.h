@@ -95,8 +95,27 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
                 ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
             }
         }
+        const bool has_res = epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES;
+#ifdef LVAE_EXP_NO_RES_PREFETCH
+        const bool res_pf = false;
+#else
+        const bool res_pf = has_res && store == LVAE_ST_ROWMAJOR;
+#endif
 #pragma unroll
         for (int a = 0; a < C::TM; ++a) {
+            // The residual values of this 32-row block are requested up front, all 4 * TN of them back to back (rows and columns are
+            // clamped to valid addresses, so the loads are unconditional): loaded next to their use, inside the divergent store
+            // guards, every one of them was a memory round trip of its own -- 15 % of an fc2 launch.
+            f32x4 rv[4][C::TN];
+            if (res_pf) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;
+                    const float* resrow = d.res + (long)(row < d.M ? row : 0) * d.ldres;
+#pragma unroll
+                    for (int b = 0; b < C::TN; ++b) rv[g][b] = *(const f32x4*)(resrow + ccol4[b]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int row = m0 + (wave_m * C::TM + a) * 32 + 4 * lh + 8 * g + lj;     // row this lane stores
@@ -119,9 +138,9 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
                     quad_transpose(v0, v1, v2, v3, lj);
                     if (rok && cok4[b]) {
                         f32x4 o = {v0, v1, v2, v3};
-                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
-                            const f32x4 rv = *(const f32x4*)(resrow + ccol4[b]);
-                            o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
+                        if (has_res) {
+                            const f32x4 r4 = res_pf ? rv[g][b] : *(const f32x4*)(resrow + ccol4[b]);
+                            o[0] += r4[0]; o[1] += r4[1]; o[2] += r4[2]; o[3] += r4[3];
                         }
                         if (SLAB) {
                             const long bytes = (long)d.M * d.N * 4;

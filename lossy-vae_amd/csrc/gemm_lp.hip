@@ -351,8 +351,26 @@ __global__ __launch_bounds__(256, (TN <= 2 && ABF ? 3 : 2)) void gemm_lp_kernel(
                 ccol4[b] = ((long)si * (d.W * rr) + sj) * cp + sc;
             }
         }
+        const bool has_res = epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES;
+#ifdef LVAE_EXP_NO_RES_PREFETCH
+        const bool res_pf = false;
+#else
+        const bool res_pf = has_res && store == LVAE_ST_ROWMAJOR;
+#endif
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            // residual values of this 32-row block: requested up front, back to back, from clamped (always valid) addresses -- loaded
+            // inside the divergent store guards each was a memory round trip of its own (gemm_common.h has the same arrangement)
+            f32x4 rvp[4][TN];
+            if (res_pf) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = m0 + (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
+                    const long rbase = (long)(row < d.M ? row : 0) * d.ldres;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) rvp[g][b] = lp_load4<OBF>(d.res, rbase + ccol4[b]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int row = m0 + (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
@@ -375,8 +393,8 @@ __global__ __launch_bounds__(256, (TN <= 2 && ABF ? 3 : 2)) void gemm_lp_kernel(
                     quad_transpose(v0, v1, v2, v3, lj);
                     if (rok && cok4[b]) {
                         f32x4 o = {v0, v1, v2, v3};
-                        if (epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES) {
-                            const f32x4 rv = lp_load4<OBF>(d.res, rbase + ccol4[b]);
+                        if (has_res) {
+                            const f32x4 rv = res_pf ? rvp[g][b] : lp_load4<OBF>(d.res, rbase + ccol4[b]);
                             o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
                         }
                         lp_store4<OBF>(d, obase + ccol4[b], o);
