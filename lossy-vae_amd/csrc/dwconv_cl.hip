@@ -1,32 +1,35 @@
 // dwconv_cl.hip -- depthwise k x k conv + bias -> LayerNorm(C) -> per-channel affine (LN weight/bias or AdaLN scale/shift) over an
 // NHWC map, "channel-per-lane" form (lvae/models/common.py:145-152; qresvae/model.py:168-176).
 //
-// The earlier forms of this operator (pointwise.hip) give every pixel to a few lanes that hold ALL its channels, because the
-// LayerNorm wants them together; the k*k weights of so many channels do not fit in registers, so their tap loop is fed from LDS and
-// is bound by LDS fragment reads (17 ds_read_b128 per 56 packed FMAs: DESIGN.md 5b).  Here the roles are swapped:
-//   * a lane owns ONE CHANNEL of an 8-pixel-wide column strip and keeps its k*k weights in registers (49 VGPRs at k = 7); a wave is
-//     64 channels of one strip, a workgroup the C/64 waves of that strip.  Two horizontally adjacent output pixels share one
-//     v_pk_fma_f32 (the weight is broadcast to both halves with op_sel_hi; at k = 7 every second weight sits in a high half and is
-//     applied with two scalar FMAs -- see pk_fma_wlo); the pixel pairs that start at an odd column are assembled with two moves --
-//     64-bit operands must be even-aligned;
-//   * a workgroup produces a tile of 8 x TH output pixels: the TH + k - 1 input rows are visited ONCE, top to bottom (8 + k - 1
-//     pixels per lane and row), and each feeds the up to k output rows it
-//     belongs to; TH x 8 accumulators per lane.  The whole tile is straight-line code (every register index static, no phi copies).
-//     No LDS reads in the tap loop, no weight traffic.  Rows reach the registers through wave-private LDS row buffers filled by DMA
-//     two rows ahead (see dma_row / read_row).  Taps are visited column-major inside a row, which leaves every output's
-//     accumulation order -- bias, then taps (i, j) ascending -- unchanged;
+// The sliding-window kernel of pointwise.hip (and the LDS-tiled forms that preceded this file) give every pixel to a few lanes that
+// hold ALL its channels, because the LayerNorm wants them together; the k*k weights of so many channels do not fit in registers, so
+// the tap loop is fed from memory / LDS and is bound by fragment reads (17 ds_read_b128 per 56 packed FMAs: DESIGN.md 5b).  Here
+// the roles are swapped:
+//   * a lane owns ONE CHANNEL of an 8-pixel-wide column strip and keeps its k*k weights in registers (49 weights in 25 register pairs
+//     at k = 7); a wave is 64 channels of one strip, a workgroup the C/64 waves of that strip.  Two horizontally adjacent output
+//     pixels share one v_pk_fma_f32 (the weight is broadcast to both halves with op_sel_hi; at k = 7 every second weight sits in a
+//     high half and is applied with two scalar FMAs -- see pk_fma_wlo); the pixel pairs that start at an odd column are assembled
+//     with two moves -- 64-bit operands must be even-aligned;
+//   * a workgroup produces tiles of 8 x TH output pixels: the TH + k - 1 input rows of a tile are visited ONCE, top to bottom
+//     (8 + k - 1 pixels per lane and row), and each feeds the up to k output rows it belongs to; TH x 8 accumulators per lane.  A tile
+//     is straight-line code (every register index static).  No memory access in the tap loop.  Rows reach the registers through
+//     wave-private LDS row buffers filled by DMA two rows ahead (dma_row / read_row).  Taps are visited column-major inside a row,
+//     which leaves every output's accumulation order -- bias, then taps (i, j) ascending -- unchanged;
 //   * a finished output row is transposed through a wave-private LDS tile into a pixel-major layout (8 lanes per pixel, 8 channels
-//     per lane: 16-B accesses, 128 B contiguous per pixel and store), where the two-pass LayerNorm statistics cost 7 adds + 3 DPP
-//     steps per lane; the C/64 waves exchange their per-pixel partial sums through LDS (two workgroup barriers per output row).
+//     per lane: 16-B accesses, 128 B contiguous per pixel and store) for the LayerNorm: 7 adds + 3 DPP steps per lane and
+//     statistic; the C/64 waves exchange per-pixel (mean, M2) pairs through LDS -- ONE workgroup barrier per output row, and the
+//     part after it is placed inside the next row's taps (ln_local / ln_finish).
 // Zero padding comes from the buffer unit: a row's resource descriptor covers exactly that image row (num_records = 0 for rows outside
-// the image), so columns left / right of the image and rows above / below read as hardware zeros without masks on the data path.
-// TH (8, 4 or 1 output rows per workgroup; k - 1 halo rows are re-read per tile, from L2) only changes the parallelism, never an
-// output bit, so the launcher picks it from the map size.
+// the image), so columns left / right of the image and rows above / below read as hardware zeros without masks on the data path
+// (LDS-DMA writes zeros for out-of-range lanes: tools/ubench/lds_dma_oob.hip).
+// TH (8, 4 or 1 output rows per tile; k - 1 halo rows are re-read per tile, from L2) and the tiles per workgroup only change the
+// parallelism, never an output bit, so the launcher picks them from the map size.
 //
 // Arithmetic: the conv chain is the earlier kernels' (same bits); the LayerNorm uses THIS kernel's association (per wave: mean and
 // centred sum of squares of its 64 channels -- 8 channels in a lane, 8 lanes by xor 1, xor 2, half-mirror -- merged over the waves in
-// ascending order by the parallel-variance identity) and rstd = v_rsq_f32 refined by one Newton step (the earlier forms: 1 / sqrtf),
-// so the operator is dispatched to this kernel by (C, k) alone -- never by batch or map size: batch-of-8 == 8 single images, and the encoder and the decoder see the same bits.
+// ascending order by the parallel-variance identity) and rstd = v_rsq_f32 refined by one Newton step (the other kernel: 1 / sqrtf),
+// so the operator is dispatched to this kernel by (C, k) alone -- never by batch or map size: batch-of-8 == 8 single images, and the
+// encoder and the decoder see the same bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
