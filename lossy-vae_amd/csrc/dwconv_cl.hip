@@ -422,6 +422,7 @@ int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const fl
     if (g_dw_cl == 0) return 0;
     if (ln_w && shift) return 0;
     if (!(C == 128 || C == 192 || C == 256 || C == 384 || C == 512) || !(k == 1 || k == 3 || k == 5 || k == 7)) return 0;
+    if ((long)H * W * C * (bf16 ? 2 : 4) > 0x7fffffffL) return 0;      // one image's map must fit a buffer descriptor (2 GiB)
     const float* aw = ln_w ? ln_w : scale1p;
     const float* ab = ln_w ? ln_b : shift;
     if (bf16) { *rc = lvae_dwln_cl_launch_bf16(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
