@@ -220,7 +220,8 @@ int launch_w8(const lvae_gemm_desc* d, hipStream_t st) {
 // 0,2,4,6,1,3,5,7 so that every LDS write group (16 lanes b64 / 8 lanes b128) covers 32 distinct banks with 112-B rows.
 // Per accumulator: k16 steps in ascending k, six cross terms in gemm_x3_kernel's order => bit-identical to it.
 template <int TN, bool AGELU, int AMODE>
-__global__ __launch_bounds__(256, 2) void gemm_x3k16_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
+// (TN = 1: three waves per SIMD -- what its 43 KB of LDS allow; without the bound the epilogue's residual prefetch cost it the third)
+__global__ __launch_bounds__(256, (TN == 1 ? 3 : 2)) void gemm_x3k16_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     using C = Cfg<2, 2, 2, TN, 1, 32>;
     constexpr int ROWB = 112, ROWS = 128 + 64 * TN, STAGE = ROWS * ROWB;
     constexpr int NWC = 384 * TN, NW = (NWC + 255) / 256;          // 16-B W chunks per stage, per thread (wrap-around duplicates)
