@@ -149,7 +149,9 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
  * y*(1+scale)+shift, one pass over an NHWC map (common.py:145-152).  wt is [k*k][C] (tap-major), `ln_w`/`ln_b`
  * (optional, may be NULL) are the LayerNorm affine of qres34m's MyConvNeXtBlock (qresvae/model.py:168-182);
  * `shift`/`scale1p` (optional) are the per-lambda AdaLN vectors with scale1p = 1+scale.
- * Supported: k in {1,3,5,7}; C in {128,192,256,384,512}.  Returns -22 for unsupported shapes. */
+ * Supported: k in {1,3,5,7}; C in {128,144,192,256,288,384,512}.  Returns -22 for unsupported shapes.
+ * The bits of an output pixel depend on (C, k, which affines are given) only -- not on B, H, W or the launch geometry:
+ * C in {128,192,256,384,512} with at most one affine runs csrc/dwconv_cl.hip, everything else the sliding-window kernel. */
 int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                        const float* shift, const float* scale1p, float* y,
                        int B, int H, int W, int C, int k, void* stream);
