@@ -11,8 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lvae', '_native')
 OUT = os.path.join(OUT_DIR, 'liblvae_hip.so')
-SOURCES = ['gemm_f32.hip', 'gemm_x3v2.hip', 'gemm_lp.hip', 'pointwise.hip', 'dwconv_cl.hip', 'dwconv_cl_bf16.hip', 'rans_host.cpp']
-HEADERS = ['gemm_common.h', 'device_math.h', 'dwconv_cl.hip']       # dwconv_cl.hip is also #included by dwconv_cl_bf16.hip
+SOURCES = ['gemm_f32.hip', 'gemm_f32_patch2.hip', 'gemm_f32_conv3.hip', 'gemm_x3v2.hip', 'gemm_lp.hip', 'pointwise.hip', 'dwconv_cl.hip', 'dwconv_cl_bf16.hip', 'rans_host.cpp']
+HEADERS = ['gemm_common.h', 'device_math.h']
+INCLUDED = {'dwconv_cl_bf16.hip': 'dwconv_cl.hip', 'gemm_f32_patch2.hip': 'gemm_f32.hip', 'gemm_f32_conv3.hip': 'gemm_f32.hip'}   # wrapper -> the source it #includes
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lvae_hip.h')
 
 
@@ -35,7 +36,8 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT_DIR, s + '.o')
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+        src_t = max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, INCLUDED[s])) if s in INCLUDED else 0)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(src_t, hdr_t):
             continue
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
         if s.endswith('.cpp'):

@@ -587,7 +587,14 @@ typedef Cfg<2, 2, 1, 1, 2, 64> CfgS64;   // 64 x 64, BK 64
 typedef Cfg<2, 2, 2, 1, 2, 64> CfgB64;   // 128 x 64, BK 64
 
 constexpr int kCUs = 256;
-int g_force_cfg = -1;      // tuning hook (LVAE_GEMM_CFG env var): force a tile configuration id for N > 64
+}  // namespace
+// tuning hook (LVAE_GEMM_CFG env var): force a tile configuration id for N > 64; one object for the three translation units below
+#ifdef LVAE_GEMM_TU_AMODE
+extern int g_force_cfg;
+#else
+int g_force_cfg = -1;
+#endif
+namespace {
 
 // Estimated cost (arbitrary units ~ MFMA cycles on the critical CU) of running the problem with a BMxBN tile:
 // rounds of tiles over the CUs (workgroup slots) x per-tile work, plus a per-tile fixed cost (prologue + epilogue).
@@ -645,6 +652,17 @@ int launch_mode(const lvae_gemm_desc* d, hipStream_t st) {
     }
 }
 
+// This source is compiled three times (build_native.py): as is (plain-A instances + every entry point) and, through gemm_f32_patch2.hip /
+// gemm_f32_conv3.hip, with LVAE_GEMM_TU_AMODE = 1 / 2 (the 2x2-patch and 3x3-tap gather instances of the 12 tile configurations x 3
+// arithmetics) -- one translation unit with all 108 kernel instances took four minutes to compile.
+#ifdef LVAE_GEMM_TU_AMODE
+}  // namespace
+#if LVAE_GEMM_TU_AMODE == 1
+int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st) { return launch_mode<LVAE_A_PATCH2>(d, st); }
+#else
+int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st) { return launch_mode<LVAE_A_CONV3>(d, st); }
+#endif
+#else
 // split-K second pass (d.cnt == NULL only): one thread per 16-B chunk of the whole output
 __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -659,6 +677,8 @@ __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
+int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st);                        // gemm_f32_patch2.hip
+int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st);                         // gemm_f32_conv3.hip
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn);
 static int gemm_dispatch(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) { return gemm_dispatch_impl(d, st, x3v2, x3v2_tn); }
@@ -722,10 +742,11 @@ static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2,
             return launch_mode<LVAE_A_PLAIN>(d, st);
         case LVAE_A_PATCH2:
             if ((d->K0 & 3) || d->K != 4 * d->K0 || d->H <= 0 || d->W <= 0) return -22;
-            return launch_mode<LVAE_A_PATCH2>(d, st);
+            return lvae_gemm_launch_patch2(d, st);
         case LVAE_A_CONV3:
             if ((d->K0 & 3) || d->K != 9 * d->K0 || d->H <= 0 || d->W <= 0) return -22;
-            return launch_mode<LVAE_A_CONV3>(d, st);
+            return lvae_gemm_launch_conv3(d, st);
     }
     return -22;
 }
+#endif  // LVAE_GEMM_TU_AMODE
