@@ -151,6 +151,40 @@ def test_config3_qres34m_512x768_against_oracle():
         assert err <= 1e-4, err
 
 
+def test_config2_qarv_base_512x768_against_oracle():
+    """BASELINE config 2's geometry (512x768) on `qarv_base`: HIP path vs the CPU oracle on the same seeded weights and image.  No golden
+    at this size; judged like the qres34m test above on first-order flips (the blocks up to and including the first symbol flip)."""
+    from conftest import load_seeded_into, parity_record
+    from oracle import qarv_oracle
+    import lvae
+    sd = seeded_init.seeded_state_dict(qarv_oracle.qarv_param_shapes(qarv_oracle.qarv_base_arch()), seed=0)
+    m = lvae.get_model('qarv_base')
+    load_seeded_into(m, sd)
+    m = m.to('cuda:0').eval()
+    m.compress_mode()
+    orc = qarv_oracle.QarvOracle(sd)
+    orc.compress_mode()
+    im = torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, 33)).permute(2, 0, 1).float().div(255).unsqueeze(0)
+    lmb = 2048.0
+    tr = m.encode_trace(im.cuda(), lmb)
+    otr = orc.encode_trace(im, lmb, code=False)
+    n = flips = iflips = n1 = f1 = 0
+    clean = True
+    for a, b in zip(tr, otr['blocks']):
+        sf = int((a['symbols'].reshape(-1) != b['symbols'].numpy().reshape(-1)).sum())
+        xf = int((a['indexes'].reshape(-1) != b['indexes'].numpy().reshape(-1)).sum())
+        n += a['symbols'].size; flips += sf; iflips += xf
+        if clean:
+            n1 += a['symbols'].size; f1 += sf + xf
+            clean = sf == 0
+    parity_record('qarv_base 512x768 lmb=2048 vs LIVE ORACLE (no golden)', flips, iflips, n, None, flips + iflips == 0)
+    assert n == 617472                                   # SURVEY Appendix B: symbols per 512x768 image
+    assert n1 > 3072 + 2 * 12288 and f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
+    assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
+    s1 = m.compress(im.cuda(), lmb)
+    assert torch.equal(m.decompress(s1), m.decompress(m.compress(im.cuda(), lmb)))      # round trip is deterministic
+
+
 # ------------------------------------------------------------------------------------------------------------------ config 4
 def _sharded_worker(rank, world, dataset, ckpt, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
