@@ -141,7 +141,8 @@ def test_config3_qres34m_512x768_against_oracle():
     xhat = m.decompress(obj).cpu()
     x_orc = orc.decompress(obj)                         # oracle decoder on the GPU's strings: same latents unless a prior flips
     err = float((xhat - x_orc).abs().max())
-    parity_record('qres34m 512x768 vs LIVE ORACLE (no golden)', flips, iflips, n, err if flips + iflips == 0 else None, flips + iflips == 0)
+    parity_record(f'qres34m 512x768 vs LIVE ORACLE (no golden; first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, err if flips + iflips == 0 else None, flips + iflips == 0)
     assert n == 1536 + 2 * 5376 + 3 * 18432 + 3 * 61440 + 3 * 196608           # symbols per block, 512x768
     # (the oracle is PyTorch on the box's CPU, whose last bits vary between hosts: where the first symbol flip lands is not pinned;
     #  on the hosts seen so far it is block 9 or 10 of 12, i.e. n1 >= 450 000)
@@ -177,7 +178,8 @@ def test_config2_qarv_base_512x768_against_oracle():
         if clean:
             n1 += a['symbols'].size; f1 += sf + xf
             clean = sf == 0
-    parity_record('qarv_base 512x768 lmb=2048 vs LIVE ORACLE (no golden)', flips, iflips, n, None, flips + iflips == 0)
+    parity_record(f'qarv_base 512x768 lmb=2048 vs LIVE ORACLE (no golden; first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, None, flips + iflips == 0)
     assert n == 617472                                   # symbols per 512x768 image
     assert n1 > 3072 + 2 * 12288 and f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
     assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
