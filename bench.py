@@ -171,7 +171,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3)
-    ap.add_argument('--precision', type=str, default='bf16x3', choices=['fp32', 'bf16x3', 'bf16', 'fp8'],
+    ap.add_argument('--precision', type=str, default='bf16x3', choices=['fp32', 'f16x2', 'bf16x3', 'bf16', 'fp8'],
                     help="GEMM arithmetic: bf16x3 (default) = fp32-class accuracy from exact 3-term bf16 splits on the bf16 MFMA; "
                          "fp32 = exact fp32 MFMA; bf16 = operands rounded to bf16; fp8 = BASELINE config 5: bf16 activation storage + "
                          "MX-fp8 MFMA (bf16 / fp8 are not parity paths)")
@@ -278,7 +278,7 @@ def main():
         """Algorithmic HBM bytes of one GEMM launch: A and the result (+ the residual rows) once, the weights once."""
         ea = 2 if d.a_bf16 else 4
         eo = 2 if d.out_bf16 else 4
-        ew = {0: 4, 1: 2, 2: 6, 3: 1}[d.prec]
+        ew = {0: 4, 1: 2, 2: 6, 3: 1, 4: 4}[d.prec]
         return ea * d.M * d.K + ew * d.N * d.K + eo * d.M * d.N * (2 if d.epi in (2, 3) else 1)
 
     def any_gemm(fn, a, label):
@@ -331,6 +331,13 @@ def main():
         elif args.precision == 'fp32':
             roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<Cfg<*>, 0> (PLAIN GEMM launches: MLP fc1/fc2 + 1x1 convs; v_mfma_f32_32x32x2_f32)',
                     'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **common}
+        elif args.precision == 'f16x2':
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0           # fp16 MFMA peak = bf16 MFMA peak; 3 MFMAs per fp32-accurate product step
+            roof = {'bound': 'mfma', 'kernel': 'gemm_h2_kernel<TN, *, 0> (PLAIN GEMM launches; v_mfma_f32_32x32x16_f16 x 3 cross terms)',
+                    'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'peak_note': '2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product step (hi*hi, hi*lo, lo*hi of a 2-term '
+                                 f'fp16 split); the same launches against the bf16x3 roof (416.7): {ach / (PEAK_BF16_MFMA_TFLOPS / 6.0):.3f}, '
+                                 f'against the fp32 MFMA peak (157.3): {ach / PEAK_FP32_MFMA_TFLOPS:.3f}', **common}
         else:
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0           # algorithmic fp32 FLOPs vs the dense bf16 MFMA peak / 6 MFMAs per product step
             roof = {'bound': 'mfma', 'kernel': 'gemm_x3k16_kernel<TN> / gemm_x3w8_kernel / gemm_x3_kernel<Cfg<*>, 0> (PLAIN GEMM launches; '
@@ -386,6 +393,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16x3': 'f32 (exact 3-term bf16 split of every fp32 operand, 6 bf16 MFMAs per product step, '
                                                'fp32 accumulate: fp32-class accuracy, parity-tested)',
+                      'f16x2': 'f32 (2-term fp16 split of every fp32 operand, hi + lo*2^-11 = 23 of 24 significant bits; 3 fp16 MFMAs per '
+                               'product step in two fp32 accumulators: fp32-class accuracy, parity-tested)',
                       'bf16': 'bf16-mfma (f32 activations/accumulate; NOT the parity path)',
                       'fp8': 'mxfp8-mfma (OCP e4m3 + E8M0 block scales, f32 accumulate) with bf16 activation storage: BASELINE config 5, '
                              'NOT the parity path'}[args.precision], 'data': 'synthetic',

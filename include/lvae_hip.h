@@ -122,6 +122,12 @@ typedef struct {
                                                 OCP MX-fp8 (e4m3 + one E8M0 scale per 32 k) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32
                                                 accumulate; Wt16 = [N][ldw] e4m3 bytes then [N][ldw/32] scale bytes, ldw = K rounded
                                                 up to 64 (zero padded; lvae.models.base.pack_mxfp8).  Not a parity path */
+                                          /* 4: "f16x2": each fp32 operand split into hi + lo' * 2^-11 fp16 terms (23 of fp32's 24
+                                                significant bits), three cross-term fp16 MFMAs per step (hi*hi | hi*lo' + lo'*hi in a
+                                                second fp32 accumulator) -- fp32-class accuracy at half the matrix-pipe time of prec 2;
+                                                operands must stay below 65504 in magnitude.  PLAIN (incl. [A0 | A1]) and CONV3 A modes,
+                                                K % 32 == 0, ldw == K; Wt16 = [N][K/16][2][16] fp16 (lvae.models.base.pack_f16x2).
+                                                Selected by the host per GEMM (csrc/gemm_h2.hip) */
     const unsigned short* Wt16;           /* prec 1: weights as bf16 bit patterns, [N][K], row stride ldw;
                                              prec 2: three such planes hi | mid | lo, plane stride N*ldw elements,
                                              followed -- when K % 32 == 0 and ldw == K -- by the same values in

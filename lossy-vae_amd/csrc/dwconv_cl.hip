@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
 }
 
 }  // namespace
-// tuning hook LVAE_DW_CL: 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 4 / 8) = force, -1 = heuristic
+// tuning hook LVAE_DW_CL (experimental builds only): 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 4 / 8) = force, -1 = heuristic
 #ifdef LVAE_CL_BF16_TU
 extern int g_dw_cl;
 #else
@@ -417,12 +417,16 @@ int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const
 // in (C, k, which pointers are given) only, because this kernel's LayerNorm association differs from the other forms'.
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
                      const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc) {
-    static bool env_read = false;
+#ifdef LVAE_EXPERIMENTAL_BUILD      // tools/build_exp.sh copies only: the kernel family is part of the bitstream contract (its LayerNorm
+    static bool env_read = false;   // association differs from the sliding-window kernel's), so the product library has no switch
     if (!env_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); env_read = true; }
     if (g_dw_cl == 0) return 0;
+#endif
     if (ln_w && shift) return 0;
     if (!(C == 128 || C == 192 || C == 256 || C == 384 || C == 512) || !(k == 1 || k == 3 || k == 5 || k == 7)) return 0;
-    if ((long)H * W * C * (bf16 ? 2 : 4) > 0x7fffffffL) return 0;      // one image's map must fit a buffer descriptor (2 GiB)
+    // one image's map must fit a buffer descriptor (2 GiB, > 44 Mpixels at stride 4): an argument error, NOT a silent switch to the
+    // other kernel family (whose bits differ)
+    if ((long)H * W * C * (bf16 ? 2 : 4) > 0x7fffffffL) { *rc = -22; return 1; }
     const float* aw = ln_w ? ln_w : scale1p;
     const float* ab = ln_w ? ln_b : shift;
     if (bf16) { *rc = lvae_dwln_cl_launch_bf16(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }

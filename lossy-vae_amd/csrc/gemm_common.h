@@ -7,6 +7,15 @@
 #include "../../include/lvae_hip.h"
 #include "device_math.h"
 
+// Experiment hooks of the round-1/2 kernel studies.  LVAE_EXP_NOSPLIT / LVAE_EXP_NOSTORE / LVAE_GEMM_NOLOAD give WRONG
+// RESULTS by construction (they remove work to time what is left); the others change scheduling only.  None of them can be switched on
+// in the product build: they compile only together with -DLVAE_EXPERIMENTAL_BUILD, which tools/build_exp.sh passes for its
+// side-by-side copies under _bin/ and lossy-vae_amd/build_native.py never does.
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_NOSPLIT) || defined(LVAE_EXP_NOSTORE) || defined(LVAE_EXP_PRIO) || defined(LVAE_EXP_H2_FULLLINE) || \
+    defined(LVAE_EXP_NO_RES_PREFETCH) || defined(LVAE_EPI_PRIO) || defined(LVAE_GEMM_NOLOAD) || defined(LVAE_GEMM_TRACE) || defined(LVAE_X3V2_TRACE))
+#error "LVAE_EXP_* / *_TRACE / *_NOLOAD experiment hooks need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh); never in liblvae_hip.so"
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -303,6 +312,9 @@ __device__ __forceinline__ void gemm_finish(const lvae_gemm_desc& d, f32x16 (&ac
         }
         __syncthreads();
         if (*last) {
+            // every wave of the reducing workgroup acquires (drops its view of lines it may hold from before the ticket): the slab reads
+            // below are plain loads, and the ticket holder's fence covers its own wave only
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int rows = (d.M - m0) < C::BM ? (d.M - m0) : C::BM;
             const int cols = (d.N - n0) < C::BN ? (d.N - n0) : C::BN;       // N % 4 == 0 (checked on the host)
             const int c4n = cols >> 2;

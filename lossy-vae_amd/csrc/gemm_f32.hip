@@ -677,6 +677,7 @@ __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
+int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);        // gemm_h2.hip
 int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st);                        // gemm_f32_patch2.hip
 int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st);                         // gemm_f32_conv3.hip
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
@@ -694,7 +695,7 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     }
     if (!d || !d->A0 || (!d->Wt && !(d->prec != 0 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
-    if (d->prec < 0 || d->prec > 3) return -22;
+    if (d->prec < 0 || d->prec > 4) return -22;
     if (d->prec != 3 && (d->a_bf16 || d->out_bf16)) return -22;      // bf16 storage exists in the reduced-precision mode only
     if (d->prec == 3) {
         if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
@@ -730,6 +731,12 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
 }
 
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) {
+    if (d->prec == 4) {                  // f16x2: one kernel family; the host asks for it only where it applies (engine.h2_eligible)
+        static int h2_tn = -1;
+        if (h2_tn < 0) { const char* e = getenv("LVAE_H2_TN"); h2_tn = e ? atoi(e) : 0; }
+        int rc = 0;
+        return lvae_gemm_h2_try(d, st, h2_tn, &rc) ? rc : -22;
+    }
     if (d->prec == 2 && x3v2 && d->cfg == 0 &&
         ((d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) || d->a_mode == LVAE_A_CONV3)) {   // cfg -1: legacy kernel
         int rc = 0;

@@ -85,6 +85,21 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
     return best
 
 
+def h2_eligible(d):
+    """Does csrc/gemm_h2.hip (prec 4, f16x2) take this GEMM?  Mirrors lvae_gemm_h2_try."""
+    if d.K % 32 or d.ldw != d.K:
+        return False
+    if d.a_mode == _native.A_PLAIN:
+        if d.lda0 % 4 or d.K0 + d.K1 != d.K:
+            return False
+        if d.K1 and (not d.A1 or d.K0 % 16 or d.lda1 % 4):
+            return False
+        return True
+    if d.a_mode == _native.A_CONV3:
+        return d.K0 % 16 == 0 and d.K == 9 * d.K0 and d.K1 == 0 and d.H > 0 and d.W > 0 and d.M * d.K0 * 4 <= 0x7ffffff0
+    return False
+
+
 _ORDER = object()        # marker of a stream-ordering entry in Plan.ops
 
 
@@ -115,6 +130,7 @@ class Plan:
         self.prec = 0          # lvae_gemm_desc.prec for this plan's GEMMs (0 fp32, 1 bf16, 2 bf16x3, 3 MX-fp8 + bf16 storage)
         self.adt = torch.float32   # storage type of the feature maps (bfloat16 in the reduced-precision mode)
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
+        self.w16_x3 = None     # f16x2 plans: the bf16x3 map for the GEMMs the f16x2 kernel does not take
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
         # Independent branches on a side stream (small maps only: there the GPU is far from full and the launches of a branch are
@@ -215,6 +231,12 @@ class Plan:
         # bf16 / bf16x3 only when the plan provides the bf16 planes; exact=True forces the fp32 MFMA (pure data-movement GEMMs with
         # 0/1 weights: nearest upsampling, space-to-depth -- x*1 + 0*... must reproduce x bit for bit)
         d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
+        if self.prec == 4 and not exact and not (d.prec == 4 and h2_eligible(d)):
+            # f16x2 plans: what csrc/gemm_h2.hip does not take (2x2 patch gathers, K % 32 != 0, a weight beyond fp16's range) runs on
+            # the bf16x3 arithmetic -- decided by the GEMM's shape and weights only, so encoder and decoder, batched and single-image
+            # calls agree
+            Wt16 = self.w16_x3.get(Wt) if self.w16_x3 is not None else None
+            d.prec = 2 if (Wt16 and K % 8 == 0) else 0
         d.Wt16 = Wt16 if d.prec else None
         if self.prec == 3:
             # reduced-precision plans (BASELINE config 5): bf16 maps in HBM, MX-fp8 operands; weight rows are padded to 64 k

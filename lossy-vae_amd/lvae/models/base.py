@@ -1,6 +1,7 @@
 """Shared host-side machinery of the codecs: batch -> pipeline groups (one HIP stream + one host thread each, so that a
 group's host rANS coding overlaps the other group's GPU work), coder thread budget."""
 import functools
+import logging
 import os
 
 import torch
@@ -31,6 +32,25 @@ def pack_bf16x3(t):
         return planes.reshape(-1)
     inter = planes.view(3, n, k // 16, 16).permute(1, 2, 0, 3).contiguous()
     return torch.cat([planes.reshape(-1), inter.reshape(-1)])
+
+
+def split_f16x2(t):
+    """2-term fp16 split of an fp32 tensor: (2, *t.shape) fp16 [hi, lo'] with hi + lo' / 2048 == t up to 2^-24 |t| -- the
+    arithmetic csrc/gemm_h2.hip applies to activations: hi = f16(t) (RNE), lo' = f16((t - hi) * 2048) (the residual is exact)."""
+    hi = t.to(torch.float16)
+    lo = ((t - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def pack_f16x2(t):
+    """The prec-4 weight buffer of lvae_gemm_f32 for an [N][K] fp32 weight (K % 16 == 0): fp16 planes hi | lo' in k16-interleaved
+    order [N][K/16][2][16] -- one 16-deep stage of one row is 64 contiguous bytes.  None when a weight does not fit fp16's range
+    (the caller keeps that GEMM on the bf16x3 arithmetic)."""
+    n, k = t.shape
+    if k % 16 or not bool(torch.isfinite(t).all()) or float(t.abs().max()) >= 65504.0:
+        return None
+    planes = split_f16x2(t.float())
+    return planes.view(2, n, k // 16, 16).permute(1, 2, 0, 3).contiguous().reshape(-1)
 
 
 def pack_mxfp8(t):
@@ -84,10 +104,13 @@ class LazyW16:
             h = self.map.get(ptr)
             if h is None:
                 c = (pack_bf16x3(t) if self.mode == 'bf16x3' else pack_mxfp8(t) if self.mode == 'mxfp8'
-                     else t.to(torch.bfloat16).contiguous())
+                     else pack_f16x2(t) if self.mode == 'f16x2' else t.to(torch.bfloat16).contiguous())
+                if c is None:                       # f16x2: a weight outside fp16's range
+                    self.map[ptr] = 0
+                    return None
                 self.keep.append(c)
                 h = self.map[ptr] = c.data_ptr()
-        return h
+        return h or None
 
 
 def bf16x3_weight_map(tensors):
@@ -100,17 +123,25 @@ def bf16_weight_map(tensors):
     return m, m.keep
 
 
+def f16x2_weight_map(tensors):
+    m = LazyW16(tensors, 'f16x2')
+    return m, m.keep
+
+
 def mxfp8_weight_map(tensors):
     m = LazyW16(tensors, 'mxfp8')
     return m, m.keep
 
 
-# GEMM arithmetic of newly built models, read ONCE at import (LVAE_PRECISION=fp32|bf16|bf16x3).  A bitstream decodes only under the
-# arithmetic that produced it (the priors must match bit for bit) and the container -- the reference's, byte for byte -- does not
-# record it: the default is fixed (bf16x3), an explicit mode must be set identically on both sides (docs: DESIGN.md 4).
-DEFAULT_PRECISION = os.environ.get('LVAE_PRECISION', 'bf16x3')
-PRECISIONS = ('fp32', 'bf16', 'bf16x3', 'fp8')
+# GEMM arithmetic of newly built models.  A bitstream decodes only under the arithmetic that produced it (the priors must match bit
+# for bit) and the container -- the reference's, byte for byte -- does not record it: the default is FIXED here (no environment
+# override), another mode is an explicit `model.set_gemm_precision(...)` call that must be made identically on both sides
+# (DESIGN.md 4).  compress_mode() logs the active mode once per model.
+DEFAULT_PRECISION = 'bf16x3'
+PRECISIONS = ('fp32', 'bf16', 'bf16x3', 'f16x2', 'fp8')
+PREC_CODE = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'fp8': 3, 'f16x2': 4}        # lvae_gemm_desc.prec
 assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
+_log = logging.getLogger('lvae')
 
 
 def on_model_device(fn):
@@ -139,11 +170,53 @@ class CodecBase(nn.Module):
 
     def set_gemm_precision(self, mode):
         """'fp32': exact fp32 MFMA (fmaf chains); 'bf16x3': fp32-class accuracy from three-term bf16 splits on the bf16 MFMA
-        (2.7x less matrix-pipe time); 'bf16': operands rounded to bf16, fp32 activations in HBM; 'fp8': BASELINE config 5 --
+        (2.7x less matrix-pipe time); 'f16x2': fp32-class accuracy from two-term fp16 splits, three fp16 MFMAs per product step
+        (half of bf16x3's again; GEMMs it does not cover -- 2x2 patch gathers, K % 32 != 0 -- run as bf16x3); 'bf16': operands rounded to bf16, fp32 activations in HBM; 'fp8': BASELINE config 5 --
         activations STORED as bf16 and every channel-mixing GEMM on the block-scaled MX-fp8 MFMA (visibly different numerics,
         half the HBM traffic).  Bitstreams are only decodable in the mode that produced them (the priors must match bit for bit)."""
         assert mode in PRECISIONS
         self._prec = mode
+        self._prec_logged = None
+
+    def _log_precision(self):
+        """Called by compress_mode(): one log line per model and mode naming the arithmetic its bitstreams are tied to."""
+        if getattr(self, '_prec_logged', None) != self._prec:
+            self._prec_logged = self._prec
+            _log.info('lvae: %s codes with GEMM arithmetic %r%s -- decode with the same mode', type(self).__name__, self._prec,
+                      ' (package default)' if self._prec == DEFAULT_PRECISION else ' (set explicitly)')
+
+    # ---- test access (not on the hot path)
+    @torch.no_grad()
+    def _trace_blocks(self, pl, B, force_z=None):
+        """Run an encode plan latent block by latent block (`pl.qcuts`: the op index right after each block's quantize launch)
+        and copy out, per block, what the launches left in their buffers: symbols, indexes, pm, lv (the raw log-variance
+        parameter, before softplus), qm -- numpy arrays shaped (B, z, hw) in the coder's NCHW raster order.  force_z[li], a
+        (B, z, h, w) tensor or a pair (batch rows, (len(rows), z, h, w) tensor), overwrites the block's quantised latent before the
+        blocks below it run (teacher forcing)."""
+        out, lo = [], 0
+        for li, cut in enumerate(pl.qcuts):
+            pl.run(lo, cut)
+            lo = cut
+            if li == 0:
+                pl.fetch_range_flag()
+            torch.cuda.synchronize(pl.device)
+            if li == 0:
+                pl.raise_if_out_of_range()
+            z, hw = pl.lat_shapes[li]
+            M, o = B * hw, pl.sym_off[li]
+            prm = pl.prm_bufs[li][:M * 2 * z].view(B, hw, 2 * z)
+            nchw = lambda t: t.permute(0, 2, 1).contiguous().cpu().numpy()
+            out.append(dict(symbols=pl.sym_all[o:o + M * z].view(B, z, hw).cpu().numpy(),
+                            indexes=pl.idx_all[o:o + M * z].view(B, z, hw).cpu().numpy(),
+                            pm=nchw(prm[:, :, :z]), lv=nchw(prm[:, :, z:]),
+                            qm=nchw(pl.qm_bufs[li][:M * z].view(B, hw, z))))
+            if force_z is not None and force_z[li] is not None:
+                ld = pl.zhat_ld[li]
+                rows, zt = force_z[li] if isinstance(force_z[li], tuple) else (list(range(B)), force_z[li])
+                zt = zt.to(pl.device, torch.float32).reshape(len(rows), z, hw).permute(0, 2, 1)
+                pl.zhat_bufs[li][:M * ld].view(B, hw, ld)[rows, :, :z] = zt
+        torch.cuda.synchronize(pl.device)
+        return out
 
     def _coder_threads_per_group(self, n_groups):
         if n_groups == 1:

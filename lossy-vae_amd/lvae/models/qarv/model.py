@@ -24,7 +24,7 @@ import torch.nn as nn
 from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
-from ..base import CodecBase, on_model_device
+from ..base import CodecBase, PREC_CODE, on_model_device
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 
 EMBED_DIM = 256
@@ -192,12 +192,13 @@ class _Packed:
     def bf16_map(self, mode):
         """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
         builder would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, bf16x3_weight_map, mxfp8_weight_map, _W16_LOCK
+        from ..base import bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, mxfp8_weight_map, _W16_LOCK
         with _W16_LOCK:
             if not hasattr(self, '_w16'):
                 self._w16 = {}
             if mode not in self._w16:
-                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'fp8': mxfp8_weight_map}[mode](self.t)
+                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'f16x2': f16x2_weight_map,
+                                   'fp8': mxfp8_weight_map}[mode](self.t)
         return self._w16[mode][0]
 
 
@@ -207,8 +208,9 @@ class _NetPlan(Plan):
     def __init__(self, model, pk, B):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
-        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'fp8': 3}[model._prec]
+        self.prec = PREC_CODE[model._prec]
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
+        self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
         self.lp = self.prec == 3                # reduced precision (BASELINE config 5): feature maps stored as bf16, MX-fp8 GEMMs
         self.adt = torch.bfloat16 if self.lp else torch.float32
         self.dwln = self.lib.lvae_dwconv_ln_bf16 if self.lp else self.lib.lvae_dwconv_ln_f32
@@ -216,6 +218,7 @@ class _NetPlan(Plan):
         self.pm_bufs = []                       # per latent block prior means [M][z] (NHWC rows)
         self.qcuts = []                         # encode plans: op index right after each block's quantize launch
         self.prm_ptrs, self.zhat_ptrs, self.zhat_bufs = [], [], []  # per latent block: raw prior conv output / latent buffer (scratch may be re-grown)
+        self.prm_bufs, self.qm_bufs, self.zhat_ld = [], [], []      # test access (CodecBase._trace_blocks): tensors behind those launches
         self.lat_shapes = []                    # (z, HW)
 
     def scratch(self, M, C, hid):
@@ -258,6 +261,7 @@ class _NetPlan(Plan):
         pm = self.new(M * z)
         self.pm_bufs.append(pm)
         self.prm_ptrs.append(prm.data_ptr())
+        self.prm_bufs.append(prm)
         ioff = sum(s[0] * s[1] for s in self.lat_shapes) * B
         self.lat_shapes.append((z, H * W))
         self.idx_off.append(ioff)
@@ -365,6 +369,7 @@ class _EncPlan(_NetPlan):
                           bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w, out_bf16=0,
                           label=p + '.posterior')
                 zhat = self.buf('zhat', M * z)
+                self.qm_bufs.append(qm); self.zhat_bufs.append(zhat); self.zhat_ld.append(z)
                 self.sym_off.append(ioff)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
                                                  B, h * w, z, z), p + '.quantize')
@@ -548,6 +553,7 @@ class VariableRateLossyVAE(CodecBase):
                     else:       # all blocks share one scale table: identical rows, build once
                         dg._quantized_cdf, dg._offset, dg._cdf_length = first._quantized_cdf, first._offset, first._cdf_length
                         dg._host = None
+            self._log_precision()
         self.compressing = mode
 
     @torch.no_grad()
@@ -856,13 +862,19 @@ class VariableRateLossyVAE(CodecBase):
     # ---- debugging / test access (not on the hot path)
     @torch.no_grad()
     @on_model_device
-    def encode_trace(self, im, lmb=None):
-        """Run the encode plan and return per-block int arrays (symbols, indexes in NCHW order) for parity tests."""
+    def encode_trace(self, im, lmb=None, full=False, force_z=None):
+        """Run the encode plan and return per-block int arrays (symbols, indexes in NCHW order) for parity tests.
+        full=True adds the float tensors behind them per block -- pm, lv (raw log-variance parameter), qm, as (B, z, hw) arrays --
+        and force_z (a list of (B, z, h, w) tensors or None per block) replaces the latent a block hands on to the blocks below
+        it (teacher forcing: with the oracle's latents every block sees the oracle's inputs up to rounding noise, so a flip is
+        never the cascade of an earlier one)."""
         lmb = lmb or self.default_lmb
         B, _, H, W = im.shape
         self._prepare(); self._set_lmb(lmb)
         pl = self._plan('enc', B, H, W)
         pl.im.view(B, 3, H, W).copy_(im)
+        if full or force_z is not None:
+            return self._trace_blocks(pl, B, force_z)
         pl.run()
         pl.fetch_range_flag()
         torch.cuda.current_stream(pl.device).synchronize()

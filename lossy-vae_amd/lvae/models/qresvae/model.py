@@ -22,7 +22,7 @@ import torch.nn as nn
 from ... import _native
 from ...engine import Plan, ptr
 from ...utils import coding
-from ..base import CodecBase, on_model_device
+from ..base import CodecBase, PREC_CODE, on_model_device
 from ..entropy_coding import DiscretizedGaussian, log_spaced_table, rans_decode_streams, rans_encode_streams
 from ..qarv.model import UpParams, _conv
 
@@ -241,12 +241,12 @@ class _Packed:
     def bf16_map(self, mode):
         """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
         builder would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, bf16x3_weight_map, _W16_LOCK
+        from ..base import bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, _W16_LOCK
         with _W16_LOCK:
             if not hasattr(self, '_w16'):
                 self._w16 = {}
             if mode not in self._w16:
-                self._w16[mode] = (bf16_weight_map if mode == 'bf16' else bf16x3_weight_map)(self.t)
+                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'f16x2': f16x2_weight_map}[mode](self.t)
         return self._w16[mode][0]
 
 
@@ -256,9 +256,11 @@ class _QresPlan(Plan):
         lib, self.pk, self.B = self.lib, pk, B
         if model._prec == 'fp8':
             raise NotImplementedError("the 'fp8' mode (bf16 activation storage + MX-fp8 GEMMs, BASELINE config 5) is built for qarv_base")
-        self.prec = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[model._prec]
+        self.prec = PREC_CODE[model._prec]
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
+        self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
         self.lat_shapes, self.idx_off, self.sym_off, self.cuts = [], [], [], []
+        self.qcuts, self.prm_bufs, self.qm_bufs, self.zhat_bufs, self.zhat_ld = [], [], [], [], []   # test access (CodecBase._trace_blocks)
         nH, nW = H // 64, W // 64
         # latent I/O sizes: resolution doubles at every rate-2 upsample of the top-down path
         tot, s = 0, 1
@@ -346,11 +348,14 @@ class _QresPlan(Plan):
             self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
                                                 pk.scale_table.numel(), pk.scale_bound, B, h * w, z), p + '.prior_index')
             zhat = self.buf('zhat', M * zp)
+            self.prm_bufs.append(prm); self.zhat_bufs.append(zhat); self.zhat_ld.append(zp)
             if encode:
                 qm = self.buf('qm', M * z)
                 self.vdblock(p + '.posterior', m.posterior, f.data_ptr(), feats[h].data_ptr(), qm.data_ptr(), h, w)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(), B, h * w, z, zp),
                          p + '.quantize')
+                self.qm_bufs.append(qm)
+                self.qcuts.append(len(self.ops))
             else:
                 self.cuts.append(len(self.ops))
                 self.add(lib.lvae_dequantize_f32, (ptr(self.sym_all, ioff), pm.data_ptr(), zhat.data_ptr(), B, h * w, z, zp), p + '.dequantize')
@@ -507,6 +512,7 @@ class HierarchicalVAE(CodecBase):
                     dg._quantized_cdf, dg._offset, dg._cdf_length, dg._host = first._quantized_cdf, first._offset, first._cdf_length, None
             if isinstance(self.out_net, GaussianNLLOutParams):            # (:645-646)
                 self.out_net.update()
+            self._log_precision()
             # the packed device copy holds the scale table: one built before this call (encode_trace(), or a compress() that
             # stopped at 'Uninitialized CDFs') would keep the empty pre-update table
             self._packed, self._plans = None, {}
@@ -662,13 +668,45 @@ class HierarchicalVAE(CodecBase):
 
     @torch.no_grad()
     @on_model_device
-    def encode_trace(self, im):
+    def encode_trace(self, im, full=False, force_z=None):
+        """Per-block symbols / indexes of the encode plan (parity tests); `full` / `force_z` as in the qarv model's encode_trace."""
         B, _, H, W = im.shape
         self._prepare()
         pl = self._plan('enc', B, H, W)
         pl.im.view(B, 3, H, W).copy_(im)
+        if full or force_z is not None:
+            return self._trace_blocks(pl, B, force_z)
         pl.run()
+        pl.fetch_range_flag()
         torch.cuda.current_stream(pl.device).synchronize()
+        pl.raise_if_out_of_range()
         sym, idx = pl.sym_all.cpu().numpy(), pl.idx_all.cpu().numpy()
         return [dict(symbols=sym[o:o + B * z * hw].reshape(B, z, hw).copy(), indexes=idx[o:o + B * z * hw].reshape(B, z, hw).copy())
                 for o, (z, hw) in zip(pl.sym_off, pl.lat_shapes)]
+
+    @torch.no_grad()
+    @on_model_device
+    def cond_sample(self, latents, nhw_repeat=None, temprature=1.0, paint_box=None):
+        """Decoder output for GIVEN latents (reference qresvae/model.py:591-603 with every latent supplied: forward_with_latents
+        :403-417 uses them verbatim): latents[i] is a (B, z_i, h_i, w_i) tensor, e.g. what the encoder quantised.  Sampling the
+        missing latents of a partial list (temprature, paint_box) belongs to the reference's generation demos, not to the
+        compress / decompress path, and is not offered."""
+        assert paint_box is None and all(z is not None for z in latents), 'cond_sample: every latent must be given'
+        B, _, nH, nW = latents[0].shape
+        self._prepare()
+        pl = self._plan('dec', B, nH * 64, nW * 64)
+        assert len(latents) == len(pl.lat_shapes)
+        lo = 0
+        for li, cut in enumerate(pl.cuts[:len(pl.lat_shapes)]):
+            pl.run(lo, cut)
+            z, hw = pl.lat_shapes[li]
+            ld, M = pl.zhat_ld[li], B * hw
+            assert tuple(latents[li].shape[:2]) == (B, z) and latents[li][0, 0].numel() == hw, f'latent {li}: {tuple(latents[li].shape)}'
+            zt = latents[li].to(pl.device, torch.float32).reshape(B, z, hw).permute(0, 2, 1).reshape(M, z)
+            zh = pl.zhat_bufs[li][:M * ld].view(M, ld)
+            zh.zero_()
+            zh[:, :z].copy_(zt)
+            lo = cut + 1                                 # the launch at `cut` is this block's dequantize: skipped
+        assert not pl.lossless, 'cond_sample: lossy models only (the lossless output net codes pixels, not a latent)'
+        pl.run(lo, None)
+        return pl.out.clone()

@@ -52,24 +52,33 @@ def pin_rank(device_index, local_rank=0, local_world=1, share=True):
     return len(allowed)
 
 
-def pin_ranks_collectively(device_index, dist, local_rank, local_world):
-    """pin_rank() for a whole job, with a sanity check first: every rank publishes the CPU set of its GPU's node (one tiny
-    all_gather_object); the ranks pin themselves only if those sets together cover (nearly) all CPUs the job may use -- a
-    container whose sysfs reports one node for every GPU would otherwise squeeze 8 ranks onto one socket.  Ranks sharing a node
-    split its cores evenly.  Returns the number of CPUs of this rank, or None (nothing changed)."""
+def pin_ranks_collectively(device_index, dist, local_rank=None, local_world=None, force=False):
+    """pin_rank() for a whole job, with a sanity check first: every rank publishes (hostname, CPU set of its GPU's node, CPUs it may
+    use) with one tiny all_gather_object; only the ranks of THIS host are looked at from then on (a multi-node job has identical
+    cpulists on different machines).  The ranks pin themselves only if the node sets of the host's ranks together cover (nearly) all
+    CPUs the job may use there -- a container whose sysfs reports one node for every GPU would otherwise squeeze 8 ranks onto one
+    socket (`force=True` skips that check: the 1-GPU rehearsal of the 8-rank host load, where every rank sits on one node by
+    construction).  Ranks sharing a node split its cores evenly, in global-rank order.  Returns the number of CPUs of this rank, or
+    None (nothing changed).  local_rank / local_world are accepted for compatibility and not used: the grouping comes from the gather."""
+    import socket
     mine = gpu_numa_cpus(device_index)
     allowed = sorted(os.sched_getaffinity(0))
-    sets = [None] * local_world
-    dist.all_gather_object(sets, mine)
-    if any(s_ is None for s_ in sets):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    host = socket.gethostname()
+    infos = [None] * world
+    dist.all_gather_object(infos, (host, mine, allowed))
+    here = [r for r in range(world) if infos[r][0] == host]
+    if any(infos[r][1] is None for r in here):
         return None
-    union = set().union(*[set(s_) for s_ in sets]) & set(allowed)
-    if len(union) < 0.9 * len(allowed):
+    union = set().union(*[set(infos[r][1]) for r in here]) & set(allowed)
+    if not force and len(union) < 0.9 * len(allowed):
         return None
-    sharing = [r for r in range(local_world) if sets[r] == mine]
+    sharing = [r for r in here if infos[r][1] == mine]
     cpus = sorted(set(mine) & set(allowed))
+    if not cpus:
+        return None
     per = max(1, len(cpus) // len(sharing))
-    k = sharing.index(local_rank)
+    k = sharing.index(rank) % max(1, len(cpus) // per)
     cpus = cpus[k * per:(k + 1) * per]
     try:
         os.sched_setaffinity(0, cpus)

@@ -245,6 +245,25 @@ class QresOracle:
         return obj
 
     @torch.no_grad()
+    def decode_from_latents(self, latents):
+        """cond_sample with every latent given (model.py:591-603 -> forward_with_latents :403-417, QLatentBlockX.forward_uncond
+        :284-315 with `latent` set: z = latent): the decoder output for known z, what decompress() reconstructs."""
+        nB, _, nH, nW = latents[0].shape
+        feature = self.sd['decoder.bias'].expand(nB, -1, nH, nW)
+        li = 0
+        for i, b in enumerate(self.arch['dec']):
+            p = f'decoder.dec_blocks.{i}'
+            if b[0] == 'qlb':
+                feature, pm, plogv = self.transform_prior(p, feature)
+                feature = feature + self.z_proj(p, latents[li])
+                li += 1
+                feature = my_cnx(self.sd, f'{p}.resnet_end', feature)
+            else:
+                feature = self.dec_other(p, b, feature)
+        assert li == len(latents) and 'out_net' not in self.arch
+        return feature.clone().clamp_(min=-1.0, max=1.0).mul_(0.5).add_(0.5)               # model.py:496-504
+
+    @torch.no_grad()
     def decompress(self, obj):                                                             # model.py:670-687, 440-454
         final = None
         if 'out_net' in self.arch:

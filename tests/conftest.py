@@ -10,7 +10,7 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, 'lossy-vae_amd')
-for p in (REPO, PKG):
+for p in (REPO, PKG, os.path.join(REPO, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -68,9 +68,12 @@ def product_model(qarv_seeded_sd):
 PARITY_ROWS = []
 
 
-def parity_record(case, sym_flips, idx_flips, n, max_dx, streams_identical):
+def parity_record(case, sym_flips, idx_flips, n, max_dx, streams_identical, guard=None):
+    """guard: the dict tests/parity_util.check_blocks returns (teacher-forced comparison: every flip inside its guard band, every
+    element within rounding noise) -- printed with the row."""
     PARITY_ROWS.append(dict(case=case, sym_flips=int(sym_flips), idx_flips=int(idx_flips), n=int(n),
-                            max_dx=None if max_dx is None else float(max_dx), streams_identical=bool(streams_identical)))
+                            max_dx=None if max_dx is None else float(max_dx), streams_identical=bool(streams_identical),
+                            guard=guard))
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
@@ -82,9 +85,17 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for r in PARITY_ROWS:
         dx = 'n/a' if r['max_dx'] is None else f"{r['max_dx']:.2e}"
         tr.write_line(f"{r['case']}: {r['sym_flips']}/{r['idx_flips']}/{r['n']} {dx} {'same' if r['streams_identical'] else 'DIFF'}")
+        if r.get('guard'):
+            import parity_util
+            tr.write_line('    ' + parity_util.describe(r['guard']))
     clean = sum(1 for r in PARITY_ROWS if r['sym_flips'] == 0 and r['idx_flips'] == 0)
     tr.write_line(f'{clean} of {len(PARITY_ROWS)} cases flip-free; worst max|dx| '
                   f"{max((r['max_dx'] or 0.0) for r in PARITY_ROWS):.2e} (bar 1e-4)")
+    gs = [r['guard'] for r in PARITY_ROWS if r.get('guard')]
+    if gs:
+        tr.write_line(f"guard bands: {sum(g['sym_flips'] for g in gs)} symbol + {sum(g['idx_flips'] for g in gs)} index flips in "
+                      f"{sum(g['n'] for g in gs)} teacher-forced elements, all flips inside guard band "
+                      f"(worst margins: symbol {max(g['worst_sym_margin'] for g in gs):.1e}, index {max(g['worst_idx_margin'] for g in gs):.1e})")
     try:
         out = os.path.join(REPO, 'gpurun_out')
         os.makedirs(out, exist_ok=True)

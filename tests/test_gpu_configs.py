@@ -103,10 +103,29 @@ def test_config3_eval_fix_rate_script_qres34m(offline_home, tmp_path):
     assert torch.equal(xb[1:2], m.decompress(objs[1])) and xb.shape == ims.shape
 
 
+def _free_running_flips(tr, oblocks):
+    """Symbol / index disagreements of the FREE-RUNNING encoder (each block conditioned on the GPU's own latents).  A symbol flip
+    changes the latent every later block is conditioned on, so whatever follows it is a cascade, not independent rounding events:
+    the count up to and including the first block with a symbol flip ("first-order") is returned next to the totals."""
+    n = flips = iflips = n1 = f1 = 0
+    clean = True
+    for a, b in zip(tr, oblocks):
+        sf = int((a['symbols'].reshape(-1) != b['symbols'].numpy().reshape(-1)).sum())
+        xf = int((a['indexes'].reshape(-1) != b['indexes'].numpy().reshape(-1)).sum())
+        n += a['symbols'].size; flips += sf; iflips += xf
+        if clean:
+            n1 += a['symbols'].size; f1 += sf + xf
+            clean = sf == 0
+    return n, flips, iflips, n1, f1
+
+
 def test_config3_qres34m_512x768_against_oracle():
-    """One full-size image, HIP path vs the CPU oracle on the same seeded ('wide') weights -- no golden at this size, so symbol /
-    index agreement is counted (reported in the parity summary) and the reconstruction is compared through the oracle's decoder
-    fed with the GPU's own strings."""
+    """One full-size image, HIP path vs the live CPU oracle on the same seeded ('wide') weights -- no golden at this size.
+    (1) TEACHER-FORCED comparison (parity_util.py): the HIP encoder is handed the oracle's latents block by block, every element
+    of pm / qm / ln sigma must lie within rounding noise of the oracle's and every flipped index / symbol inside its guard band;
+    (2) reconstruction: the HIP DECODER fed with the oracle's latents verbatim (cond_sample) against the oracle's decoder,
+    |dx| <= 1e-4 -- independent of any encoder-side flip; (3) free-running flip counts, reported and sanity-bounded."""
+    import parity_util
     from conftest import parity_record
     from oracle import qres_oracle
     import lvae
@@ -121,40 +140,29 @@ def test_config3_qres34m_512x768_against_oracle():
     orc = qres_oracle.QresOracle(sd)
     orc.compress_mode()
     im = torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, 31)).permute(2, 0, 1).float().div(255).unsqueeze(0)
-    tr = m.encode_trace(im.cuda())
     otr = orc.encode_trace(im, code=False)
-    # A SYMBOL flip changes the latent every later block is conditioned on, so whatever follows it is a cascade, not independent
-    # rounding events (measured: the same image has 1 + 1 flips in the last two blocks with one LayerNorm rounding and 1 + 46 + 256 with
-    # another that flips one symbol a block earlier).  Parity is therefore judged on the blocks up to and including the first one
-    # with a symbol flip ("first-order" flips); the totals are recorded and only sanity-bounded.
-    n = flips = iflips = 0
-    n1 = f1 = 0
-    clean = True
-    for a, b in zip(tr, otr['blocks']):
-        sf = int((a['symbols'].reshape(-1) != b['symbols'].numpy().reshape(-1)).sum())
-        xf = int((a['indexes'].reshape(-1) != b['indexes'].numpy().reshape(-1)).sum())
-        n += a['symbols'].size; flips += sf; iflips += xf
-        if clean:
-            n1 += a['symbols'].size; f1 += sf + xf
-            clean = sf == 0
-    obj = m.compress(im.cuda())
-    xhat = m.decompress(obj).cpu()
-    x_orc = orc.decompress(obj)                         # oracle decoder on the GPU's strings: same latents unless a prior flips
-    err = float((xhat - x_orc).abs().max())
-    parity_record(f'qres34m 512x768 vs LIVE ORACLE (no golden; first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
-                  flips, iflips, n, err if flips + iflips == 0 else None, flips + iflips == 0)
-    assert n == 1536 + 2 * 5376 + 3 * 18432 + 3 * 61440 + 3 * 196608           # symbols per block, 512x768
-    # (the oracle is PyTorch on the box's CPU, whose last bits vary between hosts: where the first symbol flip lands is not pinned;
-    #  on the hosts seen so far it is block 9 or 10 of 12, i.e. n1 >= 450 000)
-    assert n1 > 1536 + 2 * 5376 and f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)     # first-order flips; at least 3 symbol-clean blocks
+    zs = [b['z'] for b in otr['blocks']]
+    case = 'qres34m 512x768 vs LIVE ORACLE'
+    guard = parity_util.check_blocks(case, m.encode_trace(im.cuda(), full=True, force_z=zs), otr['blocks'],
+                                     m._dg().scale_table.cpu().numpy(), m._packed.scale_bound)
+    err = float((m.cond_sample([z.cuda() for z in zs]).cpu() - orc.decode_from_latents(zs)).abs().max())
+    n, flips, iflips, n1, f1 = _free_running_flips(m.encode_trace(im.cuda()), otr['blocks'])
+    parity_record(f'{case} (free-running: first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, err, flips + iflips == 0, guard)
+    assert n == guard['n'] == 1536 + 2 * 5376 + 3 * 18432 + 3 * 61440 + 3 * 196608       # symbols per block, 512x768
+    assert err <= 1e-4, err
+    assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
     assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
-    if flips + iflips == 0:
-        assert err <= 1e-4, err
+    obj = m.compress(im.cuda())
+    assert torch.equal(m.decompress(obj), m.decompress(m.compress(im.cuda())))
 
 
-def test_config2_qarv_base_512x768_against_oracle():
-    """BASELINE config 2's geometry (512x768) on `qarv_base`: HIP path vs the CPU oracle on the same seeded weights and image.  No golden
-    at this size; judged like the qres34m test above on first-order flips (the blocks up to and including the first symbol flip)."""
+def test_config2_qarv_base_b8_512x768_against_oracle():
+    """BASELINE config 2 as stated -- `qarv_base`, a BATCH of 8 images of 512x768 -- against the live CPU oracle run on two images of
+    the batch (rows 0 and 5); no golden at this size.  Same three parts as the qres34m test above: teacher-forced guard-band proof
+    on the batched encode plan (only rows 0 and 5 are forced and compared), |dx| <= 1e-4 for the HIP decoder fed with the oracle's
+    latents (conditional_sample), free-running flip counts of the batched encoder."""
+    import parity_util
     from conftest import load_seeded_into, parity_record
     from oracle import qarv_oracle
     import lvae
@@ -165,26 +173,29 @@ def test_config2_qarv_base_512x768_against_oracle():
     m.compress_mode()
     orc = qarv_oracle.QarvOracle(sd)
     orc.compress_mode()
-    im = torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, 33)).permute(2, 0, 1).float().div(255).unsqueeze(0)
-    lmb = 2048.0
-    tr = m.encode_trace(im.cuda(), lmb)
-    otr = orc.encode_trace(im, lmb, code=False)
-    n = flips = iflips = n1 = f1 = 0
-    clean = True
-    for a, b in zip(tr, otr['blocks']):
-        sf = int((a['symbols'].reshape(-1) != b['symbols'].numpy().reshape(-1)).sum())
-        xf = int((a['indexes'].reshape(-1) != b['indexes'].numpy().reshape(-1)).sum())
-        n += a['symbols'].size; flips += sf; iflips += xf
-        if clean:
-            n1 += a['symbols'].size; f1 += sf + xf
-            clean = sf == 0
-    parity_record(f'qarv_base 512x768 lmb=2048 vs LIVE ORACLE (no golden; first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
-                  flips, iflips, n, None, flips + iflips == 0)
-    assert n == 617472                                   # symbols per 512x768 image
-    assert n1 > 3072 + 2 * 12288 and f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
+    ims = torch.stack([torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, 33 + i)).permute(2, 0, 1).float().div(255) for i in range(8)])
+    lmb, rows = 2048.0, [0, 5]
+    otrs = [orc.encode_trace(ims[r:r + 1], lmb, code=False) for r in rows]
+    oblocks = [{k: torch.cat([o['blocks'][bi][k] for o in otrs], 0) for k in ('pm', 'pv', 'qm', 'indexes', 'symbols', 'z')} for bi in range(9)]
+    case = 'qarv_base B=8 512x768 lmb=2048 rows 0,5 vs LIVE ORACLE'
+    trf = m.encode_trace(ims.cuda(), lmb, full=True, force_z=[(rows, b['z']) for b in oblocks])
+    guard = parity_util.check_blocks(case, trf, oblocks, m._dg().scale_table.cpu().numpy(), m._packed.scale_bound, rows=rows)
+    zs = [b['z'] for b in oblocks]
+    x_hip = m.conditional_sample(lmb, [z.cuda() for z in zs]).cpu()
+    x_orc = torch.cat([orc.decode_from_latents(lmb, [z[i:i + 1] for z in zs]) for i in range(len(rows))], 0)
+    err = float((x_hip - x_orc).abs().max())
+    tr = m.encode_trace(ims.cuda(), lmb)
+    n, flips, iflips, n1, f1 = _free_running_flips([{k: v[rows] for k, v in blk.items()} for blk in tr], oblocks)
+    parity_record(f'{case} (free-running: first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, err, flips + iflips == 0, guard)
+    assert n == guard['n'] == 2 * 617472                 # symbols per 512x768 image
+    assert err <= 1e-4, err
+    assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
     assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
-    s1 = m.compress(im.cuda(), lmb)
-    assert torch.equal(m.decompress(s1), m.decompress(m.compress(im.cuda(), lmb)))      # round trip is deterministic
+    # the batched strings are what single-image calls give, and the round trip is deterministic
+    strings = m.compress_batch(ims.cuda(), lmb)
+    assert strings[5] == m.compress(ims[5:6].cuda(), lmb)
+    assert torch.equal(m.decompress_batch(strings)[5:6], m.decompress(strings[5]))
 
 
 # ------------------------------------------------------------------------------------------------------------------ config 4

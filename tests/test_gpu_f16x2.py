@@ -1,0 +1,178 @@
+"""-m gpu: the f16x2 split-MFMA GEMM (prec 4, csrc/gemm_h2.hip): fp32-class accuracy against fp64 on wide-range data, exact
+agreement with an fp64 emulation of its own arithmetic up to accumulation rounding, invariance of every output bit under batch size,
+tile width, split-K and the fused gathers (what keeps encoder and decoder priors in lock-step), and the model-level golden cases."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gemm(A, lda, K0, Wt, W16, bias, out, N, M, epi=0, prec=4, gamma=None, res=None, a_gelu=0, ksplit=0, ws=None, cnt=None, K=None, **kw):
+    """K0 = length of the (first) A source; K = total reduction length (default K0), also the weights' row stride."""
+    from lvae import _native
+    K = K or K0
+    d = _native.GemmDesc()
+    d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = A.data_ptr(), lda, K0, Wt.data_ptr(), W16.data_ptr(), K
+    d.bias, d.out, d.ldo = bias.data_ptr() if bias is not None else None, out.data_ptr(), N
+    if gamma is not None:
+        d.gamma = gamma.data_ptr()
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), N
+    d.M, d.N, d.K, d.epi, d.prec, d.a_gelu = M, N, K, epi, prec, a_gelu
+    if ksplit > 1:
+        d.ksplit, d.ws = ksplit, ws.data_ptr()
+        if cnt is not None:
+            d.cnt = cnt.data_ptr()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    rc = _native.lib().lvae_gemm_f32(ctypes.byref(d), _st())
+    torch.cuda.synchronize()
+    return rc
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e-4, 300.0])
+@pytest.mark.parametrize('M,N,K,epi', [(300, 192, 384, 0), (1000, 384, 192, 1), (513, 128, 32, 3), (2048, 448, 256, 2),
+                                       (129, 96, 1024, 0), (4096, 512, 2048, 0), (777, 48, 128, 0), (24576, 384, 192, 1)])
+def test_gemm_f16x2_is_fp32_class(M, N, K, epi, scale):
+    """Error against an fp64 reference of the UNROUNDED fp32 operands: of the class of the exact fp32 MFMA path's (<= 2x + 1e-6 of
+    the output scale), on rows spanning e^+-3 in magnitude, for ordinary, tiny (fp16-subnormal hi terms) and large operands."""
+    from lvae.models.base import pack_bf16x3, pack_f16x2, split_f16x2
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)) * scale).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    W2 = split_f16x2(Wt)
+    assert float((W2[0].double() + W2[1].double() / 2048 - Wt.double()).abs().max()) <= 2 ** -23 * float(Wt.abs().max())
+    Wh, W3 = pack_f16x2(Wt), pack_bf16x3(Wt)
+    bias, gamma = (torch.randn(N, generator=g) * scale).cuda(), torch.rand(N, generator=g).cuda()
+    res = (torch.randn(M, N, generator=g) * scale).cuda()
+    ref = A.double() @ Wt.double().t() + bias.double()
+    ref = {0: ref, 1: F.gelu(ref), 2: res.double() + gamma.double() * ref, 3: res.double() + ref}[epi]
+    errs = {}
+    for prec, W16 in ((0, W3), (2, W3), (4, Wh)):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        assert _gemm(A, K, K, Wt, W16, bias, out, N, M, epi, prec, gamma=gamma, res=res) == 0
+        errs[prec] = float((out.double() - ref).abs().max())
+    print(f'M={M} N={N} K={K} x{scale:g}: max err fp32-MFMA {errs[0]:.3e}, bf16x3 {errs[2]:.3e}, f16x2 {errs[4]:.3e}')
+    assert errs[4] <= 2 * errs[0] + 1e-6 * scale
+
+
+@pytest.mark.parametrize('M,N,K', [(257, 128, 256), (1024, 64, 96 * 32), (5000, 200, 64)])
+def test_gemm_f16x2_matches_its_own_arithmetic(M, N, K):
+    """The kernel against an fp64 evaluation of exactly its three cross terms (H + X / 2048 of the split operands): what is left is
+    the fp32 rounding of the two accumulators (<= K/16 + 2 roundings of 2^-24 relative each) -- a wrong lane / k mapping, a swapped
+    plane or a missing term is orders of magnitude above it."""
+    from lvae.models.base import pack_f16x2, split_f16x2
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    A2, W2 = split_f16x2(A).double(), split_f16x2(Wt).double()
+    H = A2[0] @ W2[0].t()
+    X = A2[1] @ W2[0].t() + A2[0] @ W2[1].t()
+    ref = H + X / 2048.0
+    out = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, pack_f16x2(Wt), None, out, N, M) == 0
+    bound = (K / 16 + 4) * 2.0 ** -24 * (A.double().abs() @ Wt.double().abs().t())
+    assert bool(((out.double() - ref).abs() <= bound).all())
+    # identity: every weight comes back exactly where hi + lo' / 2048 represents it exactly (here: weights rounded to 20 bits)
+    if K <= 256:
+        Wq = (Wt * 1024).round() / 1024
+        o2 = torch.empty(K, N, device='cuda')
+        assert _gemm(torch.eye(K, device='cuda'), K, K, Wq, pack_f16x2(Wq), None, o2, N, K) == 0
+        assert torch.equal(o2, Wq.t().contiguous())
+
+
+def test_gemm_f16x2_bits_do_not_depend_on_launch_geometry():
+    """Rows of a large problem == the same rows computed alone (batch invariance, tile-row position), columns under a 128-wide and a
+    64-wide tile (N = 128 -> TN 2, N = 64 -> TN 1), a padded leading dimension, and split-K through the reduce kernel == through the
+    in-kernel last-arriver reduction."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 3000, 128, 768
+    Ab = torch.randn(M, K + 8, generator=g).cuda()
+    A = Ab[:, :K].contiguous()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Wh = pack_f16x2(Wt)
+    full = torch.empty(M, N, device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, full, N, M, 1) == 0
+    pad = torch.empty(M, N, device='cuda')
+    assert _gemm(Ab, K + 8, K, Wt, Wh, bias, pad, N, M, 1) == 0
+    assert torch.equal(full, pad)
+    for r0, n in ((0, 1), (130, 200), (2999, 1), (1024, 384)):
+        part = torch.empty(n, N, device='cuda')
+        assert _gemm(A[r0:r0 + n].contiguous(), K, K, Wt, Wh, bias, part, N, n, 1) == 0
+        assert torch.equal(part, full[r0:r0 + n])
+    W64 = Wt[:64].contiguous()
+    half = torch.empty(M, 64, device='cuda')
+    assert _gemm(A, K, K, W64, pack_f16x2(W64), bias[:64].contiguous(), half, 64, M, 1) == 0
+    assert torch.equal(half, full[:, :64].contiguous())
+    # split-K: slices summed in slice order by the reduce kernel / by the tile's last arriver
+    S = 4
+    ws = torch.empty(S * M * N, device='cuda')
+    a = torch.empty(M, N, device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, a, N, M, 1, ksplit=S, ws=ws) == 0
+    cnt = torch.zeros(4096, dtype=torch.int32, device='cuda')
+    b = torch.empty(M, N, device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, b, N, M, 1, ksplit=S, ws=ws, cnt=cnt) == 0
+    assert torch.equal(a, b) and int(cnt.abs().sum()) == 0
+    ref = F.gelu(A.double() @ Wt.double().t() + bias.double())
+    assert float((a.double() - ref).abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize('M,N,K0,K1', [(3000, 256, 256, 384), (260, 512, 512, 1024), (5000, 128, 16, 48)])
+def test_gemm_f16x2_concat_operand(M, N, K0, K1):
+    """A = [A0 | A1] along K (post_merge's fused torch.cat, qarv/model.py:66-67) == the same product on a materialised concatenation."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(M + N + K0 + K1)
+    K = K0 + K1
+    A0, A1 = torch.randn(M, K0 + 4, generator=g).cuda(), torch.randn(M, K1 + 8, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    Wh, bias = pack_f16x2(Wt), torch.randn(N, generator=g).cuda()
+    o1, o2 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    assert _gemm(A0, K0 + 4, K0, Wt, Wh, bias, o1, N, M, A1=A1.data_ptr(), lda1=K1 + 8, K1=K1, K=K) == 0
+    Ac = torch.cat([A0[:, :K0], A1[:, :K1]], 1).contiguous()
+    assert _gemm(Ac, K, K, Wt, Wh, bias, o2, N, M) == 0
+    assert torch.equal(o1, o2)
+    assert float((o1.double() - (Ac.double() @ Wt.double().t() + bias.double())).abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,N,epi,a_gelu', [(2, 24, 40, 256, 8, 0, 0), (3, 9, 13, 96, 96, 1, 1), (1, 64, 96, 384, 32, 0, 0),
+                                                     (5, 16, 24, 512, 96, 0, 0), (2, 7, 5, 64, 200, 3, 0)])
+def test_gemm_f16x2_conv3_gather(B, H, W, Cin, N, epi, a_gelu):
+    """3x3-tap gather (posterior heads, qres VD blocks; out-of-image taps = out-of-range buffer reads) against F.conv2d in fp64, and
+    image b of the batch == the same image alone."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(B + H + W + Cin + N)
+    M, K = B * H * W, 9 * Cin
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w4 = (torch.randn(N, Cin, 3, 3, generator=g) / K ** 0.5).cuda()
+    Wt = w4.permute(0, 2, 3, 1).reshape(N, K).contiguous()
+    Wh, bias = pack_f16x2(Wt), torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    out = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(x, Cin, Cin, Wt, Wh, bias, out, N, M, epi, res=res, a_gelu=a_gelu, a_mode=2, H=H, W=W, K=K) == 0
+    xin = F.gelu(x.double()) if a_gelu else x.double()
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w4.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    ref = {0: ref, 1: F.gelu(ref), 3: res.double() + ref}[epi]
+    assert float((out.double() - ref).abs().max()) < 3e-5
+    one = torch.empty(H * W, N, device='cuda')
+    b = B - 1
+    assert _gemm(x[b].contiguous(), Cin, Cin, Wt, Wh, bias, one, N, H * W, epi, res=res[b * H * W:].contiguous(), a_gelu=a_gelu,
+                 a_mode=2, H=H, W=W, K=K) == 0
+    assert torch.equal(one, out[b * H * W:])
+
+
+def test_gemm_f16x2_rejects_what_it_does_not_take():
+    from lvae.models.base import pack_f16x2
+    A, Wt = torch.randn(64, 48).cuda(), torch.randn(32, 48).cuda()
+    assert pack_f16x2(torch.full((4, 32), 1e5)) is None               # beyond fp16's range: the host keeps such a GEMM on bf16x3
+    out = torch.empty(64, 32, device='cuda')
+    assert _gemm(A, 48, 48, Wt, pack_f16x2(Wt), None, out, 32, 64) == -22      # K % 32 != 0

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_util
 import seeded_init
 
 pytestmark = pytest.mark.gpu
@@ -32,16 +33,17 @@ def _img(h, w, seed, kind='natural'):
 MAX_SYM_FLIPS, MAX_IDX_FLIPS = 0, 1
 
 
-@pytest.mark.parametrize('prec', ['bf16x3', 'fp32'])
+@pytest.mark.parametrize('prec', ['f16x2', 'bf16x3', 'fp32'])
 @pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
 def test_golden_symbols_and_reconstruction(product_model, golden_dir, tag, seed, prec):
-    """Both fp32-accurate GEMM arithmetics (the default 3-term bf16 split and the exact fp32 MFMA) against the reference."""
+    """The three fp32-accurate GEMM arithmetics (2-term fp16 split, 3-term bf16 split, exact fp32 MFMA) against the reference."""
     m = product_model
+    base = m._prec
     m.set_gemm_precision(prec)
     try:
         _golden_case(m, golden_dir, tag, seed, prec)
     finally:
-        m.set_gemm_precision('bf16x3')
+        m.set_gemm_precision(base)
 
 
 def _golden_case(m, golden_dir, tag, seed, prec):
@@ -89,7 +91,11 @@ def _golden_case(m, golden_dir, tag, seed, prec):
         zs = [torch.from_numpy(g[f'{key}.b{bi}.symbols']).float() + torch.from_numpy(g[f'{key}.b{bi}.pm']) for bi in range(9)]
         xz = m.conditional_sample(lmb, [z.cuda() for z in zs])
         err_z = float((xz.cpu() - torch.from_numpy(g[f'{key}.xhat'])).abs().max())
-        parity_record(case, flips, iflips, n, max(err, err_z), same)
+        # ... and every flip is a guard-band event, every other element within rounding noise (teacher-forced: parity_util.py)
+        ref_blocks = [{k: g[f'{key}.b{bi}.{k}'] for k in ('pm', 'pv', 'qm', 'indexes', 'symbols')} for bi in range(9)]
+        trf = m.encode_trace(im, lmb, full=True, force_z=zs)
+        guard = parity_util.check_blocks(case, trf, ref_blocks, m._dg().scale_table.cpu().numpy(), m._packed.scale_bound)
+        parity_record(case, flips, iflips, n, max(err, err_z), same, guard)
         assert flips <= MAX_SYM_FLIPS and iflips <= MAX_IDX_FLIPS, (case, flips, iflips, n)
         assert err <= 1e-4 and err_z <= 1e-4, (case, err, err_z)
         if same:

@@ -115,3 +115,47 @@ def test_auto_ksplit_is_batch_independent_and_valid():
     assert auto_ksplit(96, 512, 1000, RM, 512, 512, 2) == 1                # K not a multiple of 32
     assert auto_ksplit(96, 510, 1024, RM, 510, 512, 2) == 1                # N not a multiple of 4
     assert auto_ksplit(96, 512, 1024, _native.ST_SHUFFLE, 512, 512, 2) == 1
+
+
+def test_numa_pinning_groups_ranks_by_host(monkeypatch):
+    """lvae/utils/numa.pin_ranks_collectively on a faked 2-node x 4-GPU job: ranks are grouped by HOSTNAME (identical cpulists on two
+    machines must not be pooled), split their node's cores in global-rank order, and refuse a topology that covers < 90 % of the CPUs."""
+    import os
+    import socket
+    from lvae.utils import numa
+    node = {0: list(range(0, 8)), 1: list(range(8, 16))}                 # two NUMA nodes of 8 cores per machine, 2 GPUs each
+    ranks = [('hostA', node[0]), ('hostA', node[0]), ('hostA', node[1]), ('hostA', node[1]),
+             ('hostB', node[0]), ('hostB', node[0]), ('hostB', node[1]), ('hostB', node[1])]
+    allowed = set(range(16))
+    pinned = {}
+
+    class FakeDist:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def get_rank(self):
+            return self.rank
+
+        def get_world_size(self):
+            return len(ranks)
+
+        def all_gather_object(self, out, mine):
+            for r, (h, cp) in enumerate(ranks):
+                out[r] = (h, cp, sorted(allowed))
+
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(allowed))
+    for r, (h, cp) in enumerate(ranks):
+        monkeypatch.setattr(socket, 'gethostname', lambda h=h: h)
+        monkeypatch.setattr(numa, 'gpu_numa_cpus', lambda idx, cp=cp: cp)
+        monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus, r=r: pinned.__setitem__(r, list(cpus)))
+        assert numa.pin_ranks_collectively(r % 4, FakeDist(r)) == 4
+    assert pinned[0] == [0, 1, 2, 3] and pinned[1] == [4, 5, 6, 7] and pinned[2] == [8, 9, 10, 11] and pinned[3] == [12, 13, 14, 15]
+    assert [pinned[r] for r in range(4, 8)] == [pinned[r] for r in range(4)]          # the other machine: the same layout, not 8-way slices
+    # a container that reports ONE node for every GPU: nothing is pinned ... unless forced (the single-GPU rehearsal)
+    ranks[:] = [('hostA', node[0])] * 8
+    pinned.clear()
+    monkeypatch.setattr(socket, 'gethostname', lambda: 'hostA')
+    monkeypatch.setattr(numa, 'gpu_numa_cpus', lambda idx: node[0])
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus: pinned.__setitem__('x', list(cpus)))
+    assert numa.pin_ranks_collectively(0, FakeDist(3)) is None and not pinned
+    assert numa.pin_ranks_collectively(0, FakeDist(3), force=True) == 1 and pinned['x'] == [3]

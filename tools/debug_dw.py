@@ -1,5 +1,5 @@
 """Debug: encode a seeded image with qarv_base (default arithmetic) and dump the per-block symbols / indexes:
-   python tools/debug_dw.py out.npz [H W B]          (run under different LVAE_DW_CL / LVAE_GROUPS / LVAE_PRECISION and diff)
+   python tools/debug_dw.py out.npz [H W B]          (run under different LVAE_GROUPS and diff)
    python tools/debug_dw.py --diff a.npz b.npz"""
 import os, sys
 import numpy as np

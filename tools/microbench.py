@@ -45,8 +45,8 @@ def bench_gemm(M, N, K, epi):
     d.res, d.ldres, d.out, d.ldo, d.M, d.N, d.K, d.epi = res.data_ptr(), N, out.data_ptr(), N, M, N, K, epi
     prec = int(os.environ.get('LVAE_PREC', '0'))
     if prec:
-        from lvae.models.base import pack_bf16x3
-        w16 = pack_bf16x3(Wt) if prec == 2 else Wt.to(torch.bfloat16).contiguous()
+        from lvae.models.base import pack_bf16x3, pack_f16x2
+        w16 = pack_bf16x3(Wt) if prec == 2 else pack_f16x2(Wt) if prec == 4 else Wt.to(torch.bfloat16).contiguous()
         d.Wt16, d.prec = w16.data_ptr(), prec
         d._keep = w16
     t = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(d), st()))

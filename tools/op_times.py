@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-launch timing of the qarv_base encode + decode plans (single stream, HIP events around every recorded launch), grouped by
-(op, shape).  Shows where a step's GPU time goes and what each GEMM shape achieves.   python tools/op_times.py [B] [H] [W]"""
+(op, shape).  Shows where a step's GPU time goes and what each GEMM shape achieves.   python tools/op_times.py [B] [H] [W]
+(OP_TIMES_PRECISION=f16x2|bf16x3|fp32|bf16|fp8 selects the GEMM arithmetic; default: the package default)"""
 import ctypes
 import os
 import sys
@@ -35,6 +36,8 @@ def main():
         model.load_state_dict(sd)
         model.compress_mode()
         model = model.to(dev).eval()
+    if os.environ.get('OP_TIMES_PRECISION'):              # tool-side switch (the package itself has no environment override)
+        model.set_gemm_precision(os.environ['OP_TIMES_PRECISION'])
     model.pipeline_groups = 1
     ims = bench.synth_batch(B, H, W, 0).to(dev)
     strings = model.compress_batch(ims)

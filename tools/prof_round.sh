@@ -34,5 +34,5 @@ DW_ONLY=3 bash $R/tools/pmc_dw.sh > $O/pmc_dwconv_ln_cl.txt 2>&1
 # 8. per-op tables (single stream, HIP events around every launch)
 python $R/tools/op_times.py 8 2>&1 | grep -v amdgpu > $O/op_times_b8.txt
 python $R/tools/op_times.py 1 2>&1 | grep -v amdgpu > $O/op_times_b1.txt
-LVAE_PRECISION=fp8 python $R/tools/op_times.py 8 2>&1 | grep -v amdgpu > $O/op_times_fp8.txt
+OP_TIMES_PRECISION=fp8 python $R/tools/op_times.py 8 2>&1 | grep -v amdgpu > $O/op_times_fp8.txt
 ls -la $O
