@@ -9,8 +9,8 @@ A "step" = one pass of the hot path over one batch: compress_batch(8 images) + d
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      -- the dominant kernel family (the PLAIN channel-mixing GEMMs: MLP fc1/fc2 + 1x1 convs, 87% of the path's FLOPs):
                    algorithmic FLOPs of those launches / their HIP-event-measured durations (extra single-stream steps after the
-                   timed region).  Default arithmetic bf16x3: against 2500/6 = 416.7 TFLOP/s (six bf16 MFMAs per fp32-accurate
-                   product step); --precision fp32: against the 157.3 TFLOP/s fp32 MFMA peak; --precision bf16 / fp8: HBM-bound,
+                   timed region).  Default arithmetic f16x2: against 2500/3 = 833.3 TFLOP/s (three fp16 MFMAs per fp32-accurate
+                   product step); --precision bf16x3: 2500/6 = 416.7; --precision fp32: the 157.3 TFLOP/s fp32 MFMA peak; bf16 / fp8: HBM-bound,
                    algorithmic bytes against 8 TB/s.  `traffic` (HBM bytes per launch) cannot be read from inside this process: it
                    is copied from the committed rocprofv3 --pmc passes of the same command and labelled so (`traffic_source`);
   roofline_e2e  -- the whole step: algorithmic GEMM FLOPs of one step / ms_per_step against both matrix peaks;
@@ -171,8 +171,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3)
-    ap.add_argument('--precision', type=str, default='bf16x3', choices=['fp32', 'f16x2', 'bf16x3', 'bf16', 'fp8'],
-                    help="GEMM arithmetic: bf16x3 (default) = fp32-class accuracy from exact 3-term bf16 splits on the bf16 MFMA; "
+    ap.add_argument('--precision', type=str, default='f16x2', choices=['fp32', 'f16x2', 'bf16x3', 'bf16', 'fp8'],
+                    help="GEMM arithmetic: f16x2 (default) = fp32-class accuracy from 2-term fp16 splits, 3 fp16 MFMAs per product step; "
+                         "bf16x3 = the same from exact 3-term bf16 splits (6 MFMAs); "
                          "fp32 = exact fp32 MFMA; bf16 = operands rounded to bf16; fp8 = BASELINE config 5: bf16 activation storage + "
                          "MX-fp8 MFMA (bf16 / fp8 are not parity paths)")
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the main cpu_baseline row (0 = physical cores)')
@@ -361,7 +362,7 @@ def main():
                                       'counted by the memory-side counters')
 
     fp32_mode = None
-    if world == 1 and args.fp32_steps > 0 and args.precision == 'bf16x3':
+    if world == 1 and args.fp32_steps > 0 and args.precision in ('f16x2', 'bf16x3'):
         # the same workload with the exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), product configuration (two groups)
         model.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
         model.set_gemm_precision('fp32')

@@ -147,6 +147,14 @@ typedef struct {
                                              every tile shape), ZERO before the first launch; each launch leaves them zero again.
                                              Non-NULL: the last slice workgroup of a tile to arrive reduces the S slabs in slice order
                                              inside the GEMM launch (no second kernel; same bits).  NULL: separate reduce launch */
+    int  a_h2, out_h2;                    /* prec 4 only, "pre-split" operands in the f16x2 plane format H2K32 = [rows][K/32][2][32] fp16
+                                             (per 32 k: 32 hi terms, then 32 lo' terms; a row is K*4 bytes like its fp32 form;
+                                             lvae.models.base.pack_f16x2_k32): a_h2 = 1: A0 is such a buffer (PLAIN, K1 = 0, lda0 = K,
+                                             K % 32 == 0), written by a producer with out_h2 (lvae_dwconv_ln_h2, a GEMM) -- the GEMM then
+                                             streams both operands global -> LDS by DMA with no conversion in its main loop
+                                             (csrc/gemm_h2p.hip; Wt16 must be H2K32 as well).  out_h2 = 1: the result (ROWMAJOR,
+                                             EPI_BIAS / EPI_BIAS_GELU, N % 32 == 0, ldo = N) is stored split in that format instead
+                                             of fp32.  Same bits as splitting inside the consumer: the split is exact and unique */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
@@ -161,6 +169,13 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                        const float* shift, const float* scale1p, float* y,
                        int B, int H, int W, int C, int k, void* stream);
+
+/* The same operator with the result stored PRE-SPLIT for the f16x2 GEMM that consumes it (lvae_gemm_desc.a_h2): y is an H2K32 buffer
+ * [B*H*W][C/32][2][32] fp16 (B*H*W*C*4 bytes, like the fp32 map); value = split of exactly the fp32 result lvae_dwconv_ln_f32 gives.
+ * C in {128,192,256,384,512}, k in {1,3,5,7}, at most one affine (the csrc/dwconv_cl.hip instances); -22 otherwise. */
+int lvae_dwconv_ln_h2(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                      const float* shift, const float* scale1p, void* y,
+                      int B, int H, int W, int C, int k, void* stream);
 
 /* bf16-storage forms of the reduced-precision mode (BASELINE config 5; prec 3 of lvae_gemm_f32): x / y / out are bf16 bit patterns
  * (NHWC, 2-byte elements), arithmetic in fp32 registers, parameters fp32.  Same semantics as the _f32 entry points otherwise. */

@@ -57,6 +57,18 @@ __device__ __forceinline__ float sum8(float s) {          // total over the 8 la
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// f16x2 operand split (csrc/gemm_common.h::split_pair_h2, lvae.models.base.split_f16x2): hi = f16(x), lo' = f16((x - hi) * 2048)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_h2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 x = {x0, x1};
+    const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+    const f32x2 t = x * 2048.0f;
+    f16x2_t l;
+    l[0] = (_Float16)__builtin_fmaf((float)h[0], -2048.0f, t[0]);
+    l[1] = (_Float16)__builtin_fmaf((float)h[1], -2048.0f, t[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ unsigned f2bf_rne(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -117,7 +129,9 @@ template <int KS, int NW, int TH, bool BF> constexpr int cl_waves() {
     return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
 }
 
-template <int KS, int NW, int TH, bool BF>
+// H2 (fp32 maps only): the result is stored pre-split for the f16x2 GEMM that consumes it (lvae_gemm_desc.a_h2; format H2K32 =
+// [pixel][C/32][2][32] fp16: per 32 channels 32 hi terms, then 32 lo' terms -- 4 bytes per element like fp32) instead of as fp32.
+template <int KS, int NW, int TH, bool BF, bool H2 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_waves<KS, NW, TH, BF>(), cl_waves<KS, NW, TH, BF>()))) void dwconv_ln_cl_kernel(
     const void* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ aw,
     const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy, int tpw) {
@@ -252,7 +266,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
         f32x4 oA, oB;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { oA[e] = fmaf((lnA[e] + sh) * rstd, awA[e], abA[e]); oB[e] = fmaf((lnB[e] + sh) * rstd, awB[e], abB[e]); }
-        if (BF) {
+        if constexpr (H2) {
+            // this lane's channels chA .. chA + 3 sit at position 4 blk of 32-channel block 2 wave, chB .. + 3 at the same position of
+            // block 2 wave + 1; a block is 64 B of hi terms followed by 64 B of lo' terms
+            unsigned h0, l0, h1, l1;
+            const int base = (xs * C + 64 * wave) * 4 + 8 * blk;
+            split_pair_h2(oA[0], oA[1], h0, l0); split_pair_h2(oA[2], oA[3], h1, l1);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h0, h1}, ro, base, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, ro, base + 64, 0, 0);
+            split_pair_h2(oB[0], oB[1], h0, l0); split_pair_h2(oB[2], oB[3], h1, l1);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h0, h1}, ro, base + 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, ro, base + 192, 0, 0);
+        } else if (BF) {
             const u32x2 qa = {f2bf_rne(oA[0]) | (f2bf_rne(oA[1]) << 16), f2bf_rne(oA[2]) | (f2bf_rne(oA[3]) << 16)};
             const u32x2 qb = {f2bf_rne(oB[0]) | (f2bf_rne(oB[1]) << 16), f2bf_rne(oB[2]) | (f2bf_rne(oB[3]) << 16)};
             __builtin_amdgcn_raw_buffer_store_b64(qa, ro, (xs * C + chA) * 2, 0, 0);
@@ -328,25 +353,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
 
 }  // namespace
 // tuning hook LVAE_DW_CL (experimental builds only): 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 4 / 8) = force, -1 = heuristic
-#ifdef LVAE_CL_BF16_TU
+#if defined(LVAE_CL_BF16_TU) || defined(LVAE_CL_H2_TU)
 extern int g_dw_cl;
 #else
 int g_dw_cl = -1;
 #endif
 namespace {
 
-template <int KS, int NW, int TH, bool BF>
+template <int KS, int NW, int TH, bool BF, bool H2>
 int launch_cl_th(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
                  int tpw, hipStream_t st) {
     const int n_sx = (W + CL_SW - 1) / CL_SW, n_ty = (H + TH - 1) / TH, n_sy = (n_ty + tpw - 1) / tpw;
     const long grid = (long)B * n_sx * n_sy;
     if (grid > 0x7fffffffL || (long)H * W * 64 * NW * (BF ? 2 : 4) > 0x7fffffffL) return -22;
-    hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
+    hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF, H2>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
                        n_sx, n_sy, tpw);
     return (int)hipGetLastError();
 }
 
-template <int KS, int NW, bool BF>
+template <int KS, int NW, bool BF, bool H2>
 int launch_cl(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
               hipStream_t st) {
     // Output rows per tile (TH) and tiles per workgroup (tpw): the pair with the least estimated time.  A workgroup costs ~3 row
@@ -374,30 +399,42 @@ int launch_cl(const void* x, const float* wt, const float* bias, const float* aw
     int TH = best_th, tpw = best_tpw;
     if (g_dw_cl > 0 && (KS > 1 || g_dw_cl % 10 == 1)) { TH = g_dw_cl % 10; tpw = g_dw_cl / 10 > 0 ? g_dw_cl / 10 : 1; }   // hook: 10 * tpw + TH
     if constexpr (KS > 1) {
-        if (TH == 8) return launch_cl_th<KS, NW, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
-        if (TH >= 2) return launch_cl_th<KS, NW, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH == 8) return launch_cl_th<KS, NW, 8, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH >= 2) return launch_cl_th<KS, NW, 4, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
     }
-    return launch_cl_th<KS, NW, 1, BF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+    return launch_cl_th<KS, NW, 1, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
 }
 
-template <int KS, bool BF>
+template <int KS, bool BF, bool H2 = false>
 int launch_cl_c(int C, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H,
                 int W, hipStream_t st) {
     switch (C) {
-        case 128: return launch_cl<KS, 2, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 192: return launch_cl<KS, 3, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 256: return launch_cl<KS, 4, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 384: return launch_cl<KS, 6, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 512: return launch_cl<KS, 8, BF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 128: return launch_cl<KS, 2, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 192: return launch_cl<KS, 3, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 256: return launch_cl<KS, 4, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 384: return launch_cl<KS, 6, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 512: return launch_cl<KS, 8, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
     }
     return -22;
 }
 
 }  // namespace
 
-// This source is compiled twice (build_native.py): as is (fp32 maps + the entry point) and, through dwconv_cl_bf16.hip, with
-// LVAE_CL_BF16_TU (the bf16-map instances) -- two translation units compile in parallel, the 130 instances take minutes otherwise.
-#ifdef LVAE_CL_BF16_TU
+// This source is compiled three times (build_native.py): as is (fp32 maps + the entry point), through dwconv_cl_bf16.hip with
+// LVAE_CL_BF16_TU (the bf16-map instances) and through dwconv_cl_h2.hip with LVAE_CL_H2_TU (fp32 maps in, pre-split f16x2 planes out)
+// -- the translation units compile in parallel, the instances take minutes otherwise.
+#if defined(LVAE_CL_H2_TU)
+int lvae_dwln_cl_launch_h2(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                           int B, int H, int W, hipStream_t st) {
+    switch (k) {
+        case 1: return launch_cl_c<1, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 3: return launch_cl_c<3, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 5: return launch_cl_c<5, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 7: return launch_cl_c<7, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+    }
+    return -22;
+}
+#elif defined(LVAE_CL_BF16_TU)
 int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
                              int B, int H, int W, hipStream_t st) {
     switch (k) {
@@ -411,12 +448,15 @@ int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const
 #else
 int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
                              int B, int H, int W, hipStream_t st);
+int lvae_dwln_cl_launch_h2(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                           int B, int H, int W, hipStream_t st);
 
 // Entry point for pointwise.hip's dispatchers.  Returns 1 when this kernel takes the problem (*rc = launch status), 0 otherwise.
 // Taken for C in {128, 192, 256, 384, 512}, k in {1, 3, 5, 7} and at most ONE per-channel affine after the normalisation -- a rule
 // in (C, k, which pointers are given) only, because this kernel's LayerNorm association differs from the other forms'.
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
-                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc) {
+                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int fmt, hipStream_t st, int* rc) {
+    const int bf16 = fmt == 1;                                          // fmt: 0 fp32 maps, 1 bf16 maps, 2 fp32 in / pre-split f16x2 planes out
 #ifdef LVAE_EXPERIMENTAL_BUILD      // tools/build_exp.sh copies only: the kernel family is part of the bitstream contract (its LayerNorm
     static bool env_read = false;   // association differs from the sliding-window kernel's), so the product library has no switch
     if (!env_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); env_read = true; }
@@ -430,6 +470,7 @@ int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const fl
     const float* aw = ln_w ? ln_w : scale1p;
     const float* ab = ln_w ? ln_b : shift;
     if (bf16) { *rc = lvae_dwln_cl_launch_bf16(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
+    if (fmt == 2) { *rc = lvae_dwln_cl_launch_h2(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
     switch (k) {
         case 1: *rc = launch_cl_c<1, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;
         case 3: *rc = launch_cl_c<3, false>(C, x, wt, bias, aw, ab, y, B, H, W, st); return 1;

@@ -42,6 +42,24 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
 }
 
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// f16x2 arithmetic (prec 4): (x0, x1) -> packed fp16 pairs hi, lo' with hi + lo' / 2048 == x to 2^-24 relative -- the conversions
+// lvae.models.base.split_f16x2 applies to the weights.  hi = f16(x) (RNE); lo' = f16((x - hi) * 2048): fma(hi, -2048, x * 2048) is
+// exact before its single rounding to fp16 (x * 2048 and hi * 2048 are exact, their difference has <= 13 significant bits).
+__device__ __forceinline__ void split_pair_h2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2_t x = {x0, x1};
+    const f16x2_t h = __builtin_convertvector(x, f16x2_t);               // v_cvt_pk_f16_f32 (RNE)
+    const f32x2_t t = x * 2048.0f;
+    f16x2_t l;
+    l[0] = (_Float16)__builtin_fmaf((float)h[0], -2048.0f, t[0]);
+    l[1] = (_Float16)__builtin_fmaf((float)h[1], -2048.0f, t[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 template <int WGM_, int WGN_, int TM_, int TN_, int NBUF_ = 2, int BK_ = 32>
 struct Cfg {
     static constexpr int BK = BK_;                // k-tile depth (32, or 64 for the small latency-bound problems)
@@ -156,6 +174,15 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
                             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                                 (void*)d.out, 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs, (int)((obase + ccol4[b]) * 4), 0, 16);
+                        } else if (d.out_h2) {
+                            // pre-split result for a consumer GEMM with a_h2 (H2K32: per row and 32 columns, 32 hi terms then 32 lo')
+                            unsigned h0, l0, h1, l1;
+                            split_pair_h2(o[0], o[1], h0, l0);
+                            split_pair_h2(o[2], o[3], h1, l1);
+                            const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
+                            char* q = (char*)d.out + (obase << 2) + ((ccol4[b] >> 5) << 7) + ((ccol4[b] & 31) << 1);
+                            *(u32x2_t*)q = hi2;
+                            *(u32x2_t*)(q + 64) = lo2;
                         } else {
                             *(f32x4*)(d.out + obase + ccol4[b]) = o;
                         }

@@ -678,6 +678,7 @@ extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
 int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);        // gemm_h2.hip
+int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force_tile, int* rc);     // gemm_h2p.hip
 int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st);                        // gemm_f32_patch2.hip
 int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st);                         // gemm_f32_conv3.hip
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
@@ -697,6 +698,7 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
     if (d->prec < 0 || d->prec > 4) return -22;
     if (d->prec != 3 && (d->a_bf16 || d->out_bf16)) return -22;      // bf16 storage exists in the reduced-precision mode only
+    if (d->prec != 4 && (d->a_h2 || d->out_h2)) return -22;          // pre-split operands belong to the f16x2 arithmetic
     if (d->prec == 3) {
         if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
         if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
@@ -732,9 +734,14 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
 
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) {
     if (d->prec == 4) {                  // f16x2: one kernel family; the host asks for it only where it applies (engine.h2_eligible)
-        static int h2_tn = -1;
+        static int h2_tn = -1, h2p_tile = -1;
         if (h2_tn < 0) { const char* e = getenv("LVAE_H2_TN"); h2_tn = e ? atoi(e) : 0; }
+        if (h2p_tile < 0) { const char* e = getenv("LVAE_H2P_TILE"); h2p_tile = e ? atoi(e) : 0; }
         int rc = 0;
+        if (d->out_h2 && (d->store != LVAE_ST_ROWMAJOR || (d->epi != LVAE_EPI_BIAS && d->epi != LVAE_EPI_BIAS_GELU) || (d->N & 31) ||
+                          d->ldo != d->N || d->ksplit > 1))
+            return -22;
+        if (d->a_h2) return lvae_gemm_h2p_try(d, st, d->cfg > 0 ? d->cfg : h2p_tile, &rc) ? rc : -22;      // cfg = 10 WM + TN: force a tile
         return lvae_gemm_h2_try(d, st, h2_tn, &rc) ? rc : -22;
     }
     if (d->prec == 2 && x3v2 && d->cfg == 0 &&

@@ -28,27 +28,10 @@
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// (x0, x1) -> packed fp16 pairs hi, lo' with hi + lo' / 2048 == x to 2^-24 relative -- the conversions lvae.models.base.pack_f16x2
-// applies to the weights.
-__device__ __forceinline__ void split_pair_h2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const f32x2 x = {x0, x1};
-    const f16x2 h = __builtin_convertvector(x, f16x2);                 // v_cvt_pk_f16_f32 (RNE)
-    // lo' = f16((x - hi) * 2048) as ONE fused operation per element: fma(hi, -2048, x * 2048) is exact before its single rounding to
-    // fp16 (x * 2048 and hi * 2048 are exact, their difference has <= 13 significant bits) -- v_pk_mul_f32 + 2 x v_fma_mixlo/hi_f16
-    const f32x2 t = x * 2048.0f;
-    f16x2 l;
-    l[0] = (_Float16)__builtin_fmaf((float)h[0], -2048.0f, t[0]);
-    l[1] = (_Float16)__builtin_fmaf((float)h[1], -2048.0f, t[1]);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
 
 // TN = 1 or 2 (128 x 64 / 128 x 128 tiles): the two accumulator sets of a 128 x 192 tile (192 registers) do not fit the 256 unified
 // registers a wave has at two workgroups per CU.

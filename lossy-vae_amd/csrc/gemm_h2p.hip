@@ -1,0 +1,228 @@
+// gemm_h2p.hip -- f16x2 GEMM (prec 4) whose BOTH operands arrive pre-split in the plane format H2K32 = [rows][K/32][2][32] fp16
+// (include/lvae_hip.h: lvae_gemm_desc.a_h2): the MLP of every ConvNeXt block, fc1(y) and fc2(gelu(fc1)) (lvae/models/common.py:
+// 131-132,154), where the A operand has exactly one consumer and its producer (the depthwise+LayerNorm kernel, fc1's GELU epilogue)
+// can store hi / lo' planes instead of fp32 at the same 4 bytes per element.
+//
+// Why.  gemm_h2_kernel (gemm_h2.hip) halves the matrix-pipe time of the bf16x3 arithmetic but still converts A inside its main loop:
+// per 16-deep stage a wave issues 12 MFMAs against ~50 VALU / LDS / VMEM instructions (fp32 -> hi, lo' split, ds_writes, register
+// staging), and with two waves per SIMD every one of them competes with the other wave's MFMAs for the issue port: 220-240 TFLOP/s on
+// the large layers, 27 % of the 3-MFMA roof (profiles/r03_*).  With both operands already in MFMA operand form the main loop is
+// LDS-DMA + fragment reads + MFMAs only:
+//   * global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write, no conversion): one wave instruction moves
+//     8 rows x 128 B -- whole cache lines (a 32-deep stage of a row IS one 128-B line in H2K32); fragment-shaped 64-B pieces keep the
+//     texture-address unit twice as busy for the same bytes (cdna_hip_programming.md, "x operand through LDS in full 128-B lines");
+//   * the LDS image is lane-linear (DMA writes base + 16 * lane), so bank conflicts are avoided by permuting the SOURCE address: the
+//     16-B piece at physical position pp of stage row r holds logical piece pp ^ ((r >> 1) & 7); a ds_read_b128 lane group
+//     ({0-3,12-15,20-27}, ... : MI355X_MICROARCH.md) then covers 16 distinct bank quads for every fragment read;
+//   * NBUF LDS stages of 32 k (3 x 48 KB for the 256 x 128 tile), DMA NBUF - 1 stages ahead, ONE raw s_barrier per stage with a counted
+//     vmcnt (a __syncthreads would drain the DMA queue);
+//   * fragment reads are inline asm (hipcc would guard every LDS load that may alias a DMA in flight with vmcnt(0)) with exact lgkmcnt
+//     waits; the DMA instructions of the stage two ahead are spread between the MFMAs.
+// Tiles: 64*WM x 64*TN, 2*WM waves (wave tile 64 x 32*TN, two accumulator sets): WM = 4 -> 256 rows, one workgroup per CU;
+// WM = 2 -> 128 rows, two per CU.  Per accumulator the MFMA sequence is gemm_h2_kernel's (k16 steps ascending; X: a_lo'*w_hi, a_hi*w_lo';
+// H: a_hi*w_hi), and the producers' split is the consumer's (exact), so every output bit equals gemm_h2_kernel's on the fp32 operand.
+#include "gemm_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define H2P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int WM, int TN, int NBUF>
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
+    using C = Cfg<WM, 2, 2, TN, 1, 32>;
+    constexpr int BM = 64 * WM, BN = 64 * TN, ROWS = BM + BN, STAGE = ROWS * 128;
+    constexpr int NWAVE = 2 * WM, NG = ROWS / 8, NI = NG / NWAVE;       // DMA instructions per stage, per wave and stage
+    static_assert(NG % NWAVE == 0 && NWAVE % 2 == 0, "whole DMA instructions per wave; g has the parity of the wave");
+    static_assert(NBUF * STAGE <= 160 * 1024 / (WM == 4 ? 1 : 2), "LDS");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int t;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, r = n_tiles % 8, xcd = b % 8, loc = b / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nq = d.K / 32;
+    const int rowb = d.K * 4;                                       // bytes of one H2K32 row (A and W alike)
+    // Phase stagger (LVAE_H2P_STAGGER, off by default).  Workgroups of one launch start together and take equally long, so the chip
+    // alternates between main loops (matrix pipe busy, HBM nearly idle) and epilogues (every CU storing its tile, the matrix pipe idle).
+    // Starting every second workgroup half a main loop late -- the second resident workgroup of a CU (told by its LDS allocation
+    // base) or, with one workgroup per CU, the odd CUs -- was measured and did NOT help (0 ... -5 %): kept as a knob for the record.
+    if (stagger > 0) {
+        const bool late = WM == 4 ? ((__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4) & 1) != 0)          // HW_ID.CU_ID bit 0
+                                  : (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 6) != 0);                // LDS_ALLOC.LDS_BASE
+        if (late)
+            for (int i = 0; i < nq * stagger; ++i) __builtin_amdgcn_s_sleep(8);        // 512 cycles each
+    }
+
+    // ---- DMA side.  Wave w issues the stage's instructions g = i * NWAVE + w (i < NI): rows 8g .. 8g + 7 of the stage (A rows first).
+    const int rows_a = (d.M - m0) < BM ? (d.M - m0) : BM, rows_w = (d.N - n0) < BN ? (d.N - n0) : BN;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.A0 + (long)m0 * rowb), 0, rows_a * rowb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.Wt16 + (long)n0 * rowb), 0, rows_w * rowb, 0x00020000);
+    // lane -> (row within the instruction's 8, physical piece); logical piece = physical ^ ((stage row >> 1) & 7), stage row = 8g + r_in,
+    // g = i * NWAVE + w has the parity of w (NWAVE is even): ((8g + r_in) >> 1) & 7 = (4 (w & 1) + (r_in >> 1)) & 7
+    const int r_in = lane >> 3, pp = lane & 7;
+    const int dvoff = r_in * rowb + ((pp ^ ((4 * (wave & 1) + (r_in >> 1)) & 7)) << 4);
+    auto dma = [&](int i, int stage, int buf) {                     // i, buf: compile-time after unrolling; stage: uniform
+        const int g = i * NWAVE + wave;
+        const bool isA = g < BM / 8;                                // uniform
+        const int soff = (isA ? 8 * g : 8 * g - BM) * rowb + stage * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsW, (__attribute__((address_space(3))) void*)((char*)smem + buf * STAGE + g * 1024),
+                                                 16, dvoff, soff, 0, 0);
+    };
+
+    // ---- fragment side.  Piece (plane p, k16 step t, lane half lh) = 4p + 2t + lh, read at ((piece ^ x) << 4) of the lane's row.
+    const int xr = (li >> 1) & 7;
+    unsigned a_base[4], b_base[4];                                  // [2p + t]: byte address inside a stage
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int piece = 4 * (pt >> 1) + 2 * (pt & 1) + lh;
+        const unsigned o = (unsigned)((piece ^ xr) << 4);
+        a_base[pt] = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((char*)smem) + (wave_m * 64 + li) * 128 + o;
+        b_base[pt] = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((char*)smem) + (BM + wave_n * 32 * TN + li) * 128 + o;
+    }
+
+    f32x16 accH[2][TN], accX[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accH[a][b][r] = 0.f; accX[a][b][r] = 0.f; }
+
+    // prologue: stages 0 .. NBUF-2 in flight (a stage index beyond the last re-reads the last stage into a free buffer: every iteration
+    // then issues exactly NI instructions, which keeps the vmcnt arithmetic uniform)
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) dma(i, s < nq ? s : nq - 1, s);
+
+    f16x8 af[2][2][2], bf[2][TN][2];                                // [t][a | b][plane]
+    auto stage_body = [&](auto buf_tag, int s) {
+        constexpr int BUF = decltype(buf_tag)::value, NXT = (BUF + NBUF - 1) % NBUF;
+        // my DMA instructions of stage s have landed once at most (NBUF - 2) later stages' are outstanding; after the barrier everyone's
+        // have, and everyone is done reading the buffer of stage s - 1 (= the one stage s + NBUF - 1 goes to)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NI) : "memory");
+        LVAE_FENCE();
+        unsigned aa[4], ba[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) { aa[pt] = a_base[pt] + BUF * STAGE; ba[pt] = b_base[pt] + BUF * STAGE; }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                H2P_DSR(af[tt][a][0], aa[0 + tt], a * 4096);
+                H2P_DSR(af[tt][a][1], aa[2 + tt], a * 4096);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                H2P_DSR(bf[tt][b][0], ba[0 + tt], b * 4096);
+                H2P_DSR(bf[tt][b][1], ba[2 + tt], b * 4096);
+            }
+        }
+        const int sn = s + NBUF - 1 < nq ? s + NBUF - 1 : nq - 1;
+        int issued = 0;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            // fragments of step tt have landed when at most the (4 + 2 TN) reads of step 1 are outstanding
+            if (tt == 0) {
+                if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[0][1][0]), "+v"(af[0][1][1]),
+                                                    "+v"(bf[0][0][0]), "+v"(bf[0][0][1]), "+v"(bf[0][1][0]), "+v"(bf[0][1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[0][1][0]), "+v"(af[0][1][1]),
+                                  "+v"(bf[0][0][0]), "+v"(bf[0][0][1]));
+            } else {
+                if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0][0]), "+v"(af[1][0][1]), "+v"(af[1][1][0]), "+v"(af[1][1][1]),
+                                                    "+v"(bf[1][0][0]), "+v"(bf[1][0][1]), "+v"(bf[1][1][0]), "+v"(bf[1][1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0][0]), "+v"(af[1][0][1]), "+v"(af[1][1][0]), "+v"(af[1][1][1]),
+                                  "+v"(bf[1][0][0]), "+v"(bf[1][0][1]));
+            }
+            LVAE_FENCE();
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j == 0) {
+                        accX[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][1], bf[tt][b][0], accX[0][b], 0, 0, 0);
+                        accX[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][1], bf[tt][b][0], accX[1][b], 0, 0, 0);
+                    } else if (j == 1) {
+                        accX[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][0], bf[tt][b][1], accX[0][b], 0, 0, 0);
+                        accX[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][0], bf[tt][b][1], accX[1][b], 0, 0, 0);
+                    } else {
+                        accH[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][0], bf[tt][b][0], accH[0][b], 0, 0, 0);
+                        accH[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][0], bf[tt][b][0], accH[1][b], 0, 0, 0);
+                    }
+                    // one DMA instruction of stage s + NBUF - 1 behind each MFMA pair until all NI are out
+                    if (issued < NI) { dma(issued, sn, NXT); ++issued; }
+                    LVAE_FENCE();
+                }
+            }
+        }
+        static_assert(NI <= 6 * TN, "DMA instructions per stage must fit the MFMA pairs of a stage");
+    };
+    for (int s = 0; s < nq; s += NBUF) {
+        stage_body(std::integral_constant<int, 0>{}, s);
+        if (s + 1 < nq) stage_body(std::integral_constant<int, 1 % NBUF>{}, s + 1);
+        if (NBUF > 2 && s + 2 < nq) stage_body(std::integral_constant<int, 2 % NBUF>{}, s + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing (redundant) DMAs have landed before LDS is reused / freed
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accH[a][b][r] = __builtin_fmaf(accX[a][b][r], 1.0f / 2048.0f, accH[a][b][r]);
+    gemm_finish<C>(d, accH, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
+}
+
+template <int WM, int TN, int NBUF>
+int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * TN, LDS = NBUF * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
+    static int stagger = -1;             // experiment knob (default off: measured 0 ... -5 % on the model's shapes)
+    if (stagger < 0) { const char* e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS, st, *d, tiles_n, n_tiles, stagger);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Entry point for gemm_f32.hip's dispatcher (prec 4, a_h2 = 1).  force: 0 = choose; 10 * WM + TN = that tile (tuning hook LVAE_H2P_TILE:
+// 42 = 256 x 128, 41 = 256 x 64, 22 = 128 x 128, 21 = 128 x 64).  Every choice gives the same bits.
+int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
+    if (d->prec != 4 || !d->a_h2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || d->K0 != d->K || (d->K & 31) || d->lda0 != d->K ||
+        d->ldw != d->K || d->a_gelu || d->ksplit > 1 || (long)256 * d->K * 4 > 0x7fffffffL)
+        return 0;
+    const int M = d->M, N = d->N;
+    int sel = force;
+    if (sel != 42 && sel != 41 && sel != 22 && sel != 21) {
+        // least padded work first (N = 192: three 64-wide tiles, not two 128-wide), then the larger tile if it still fills the chip:
+        // 256-row tiles run one workgroup per CU (256 slots), 128-row tiles two (512 slots)
+        const int tn = (N % 128 == 0 || ((N + 127) / 128) * 128 - N < ((N + 63) / 64) * 64 - N + 1) ? 2 : 1;
+        const long t256 = (long)((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn));
+        sel = (t256 >= 2 * 256 ? 40 : 20) + tn;
+    }
+    switch (sel) {
+        case 42: *rc = launch_h2p<4, 2, 3>(d, st); break;
+        case 41: *rc = launch_h2p<4, 1, 3>(d, st); break;
+        case 22: *rc = launch_h2p<2, 2, 2>(d, st); break;
+        default: *rc = launch_h2p<2, 1, 3>(d, st); break;
+    }
+    return 1;
+}

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
 // dwconv_cl.hip: the channel-per-lane form (weights in registers, LDS-DMA row buffers) takes the problem by (C, k) alone; what follows
 // here is the sliding-window kernel for the other channel counts (qres17m: C = 144 / 288) and the two-affine case
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
-                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int bf16, hipStream_t st, int* rc);
+                     const float* scale1p, void* y, int B, int H, int W, int C, int k, int fmt, hipStream_t st, int* rc);
 
 extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                                   const float* shift, const float* scale1p, float* y, int B, int H, int W, int C, int k,
@@ -540,6 +540,14 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
         case 7: return dispatch_dwln_c<7>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
     }
     return -22;
+}
+
+extern "C" int lvae_dwconv_ln_h2(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                                 const float* shift, const float* scale1p, void* y, int B, int H, int W, int C, int k, void* stream) {
+    if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
+    if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    int rc = 0;
+    return lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 2, (hipStream_t)stream, &rc) ? rc : -22;
 }
 
 extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out, int B, int H, int W,
@@ -755,5 +763,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 13; }
+extern "C" int lvae_abi_version(void) { return 14; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 
@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
         ('a_gelu', C.c_int), ('prec', C.c_int), ('Wt16', C.c_void_p), ('cfg', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('a_bf16', C.c_int), ('out_bf16', C.c_int), ('cnt', C.c_void_p),
+        ('a_h2', C.c_int), ('out_h2', C.c_int),
     ]
 
 
@@ -48,6 +49,7 @@ SIGNATURES = {
     'lvae_gemm_num_configs': (_i, []),
     'lvae_gelu_f32': (_i, [_vp, _vp, _l, _vp]),
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
+    'lvae_dwconv_ln_h2': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'lvae_range_flag_f32': (_i, [_vp, _l, _f, _f, _vp, _vp]),
     'lvae_dwconv_ln_bf16': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),

@@ -131,6 +131,7 @@ class Plan:
         self.adt = torch.float32   # storage type of the feature maps (bfloat16 in the reduced-precision mode)
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.w16_x3 = None     # f16x2 plans: the bf16x3 map for the GEMMs the f16x2 kernel does not take
+        self.w16_k32 = None    # f16x2 plans: weights in the H2K32 plane format for the pre-split-operand GEMMs (csrc/gemm_h2p.hip)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.seen = set()
         # Independent branches on a side stream (small maps only: there the GPU is far from full and the launches of a branch are
@@ -210,11 +211,26 @@ class Plan:
         """Scratch buffers of side-stream ops are separate from the main stream's (they run concurrently)."""
         return name + '_side' if self.on_side else name
 
+    H2P_MIN_ROWS_PER_IMAGE = 1536      # stride-4 / 8 / 16 maps of a 512x768 image; below, the few-tile layers want split-K (gemm_h2.hip)
+
+    def mlp_h2p_ok(self, C, hid, k, n_affine=1, rows_per_image=None):
+        """f16x2 plans: can the MLP of a ConvNeXt block (dwconv+LN -> fc1 -> GELU -> fc2) run with pre-split operands -- the depthwise
+        kernel and fc1's epilogue storing hi / lo' planes (H2K32) that fc1 / fc2 stream by LDS-DMA (csrc/gemm_h2p.hip)?  A rule in the
+        block's shape and the rows of ONE image (never the batch size): the arithmetic -- hence every bit -- is the same either way
+        (tests/test_gpu_f16x2.py), the rule only picks the faster pipeline."""
+        return (self.prec == 4 and self.w16_k32 is not None and C in (128, 192, 256, 384, 512) and k in (1, 3, 5, 7) and n_affine <= 1
+                and C % 32 == 0 and hid % 32 == 0 and (rows_per_image is None or rows_per_image >= self.H2P_MIN_ROWS_PER_IMAGE))
+
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
-             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, a_bf16=None, out_bf16=None, label='gemm'):
+             r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, a_bf16=None, out_bf16=None, a_h2=False,
+             out_h2=False, label='gemm'):
         if K is None:
             K = K0 + K1
+        if a_h2:               # both operands pre-split (H2K32 planes): mlp_h2p_ok() said this GEMM qualifies
+            assert self.prec == 4 and Wt16 is None
+            Wt16 = self.w16_k32.get(Wt)
+            assert Wt16, f'{label}: weights do not fit the f16x2 planes'
         if Wt16 is None and self.w16 is not None:
             Wt16 = self.w16.get(Wt)
         d = GemmDesc()
@@ -231,7 +247,14 @@ class Plan:
         # bf16 / bf16x3 only when the plan provides the bf16 planes; exact=True forces the fp32 MFMA (pure data-movement GEMMs with
         # 0/1 weights: nearest upsampling, space-to-depth -- x*1 + 0*... must reproduce x bit for bit)
         d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
-        if self.prec == 4 and not exact and not (d.prec == 4 and h2_eligible(d)):
+        d.a_h2, d.out_h2 = int(bool(a_h2)), int(bool(out_h2))
+        if a_h2:
+            assert a_mode == _native.A_PLAIN and K1 == 0 and K % 32 == 0 and d.lda0 == K and d.ldw == K, label
+            ksplit = 1
+        if out_h2:
+            assert self.prec == 4 and store == _native.ST_ROWMAJOR and N % 32 == 0 and d.ldo == N, label
+            ksplit = 1
+        if self.prec == 4 and not exact and not a_h2 and not (d.prec == 4 and h2_eligible(d)):
             # f16x2 plans: what csrc/gemm_h2.hip does not take (2x2 patch gathers, K % 32 != 0, a weight beyond fp16's range) runs on
             # the bf16x3 arithmetic -- decided by the GEMM's shape and weights only, so encoder and decoder, batched and single-image
             # calls agree

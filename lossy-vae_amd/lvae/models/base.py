@@ -53,6 +53,23 @@ def pack_f16x2(t):
     return planes.view(2, n, k // 16, 16).permute(1, 2, 0, 3).contiguous().reshape(-1)
 
 
+def pack_f16x2_k32(t):
+    """An [N][K] fp32 matrix (K % 32 == 0) in the plane format H2K32 = [N][K/32][2][32] fp16 (include/lvae_hip.h: lvae_gemm_desc.a_h2):
+    per row and 32 k, the 32 hi terms then the 32 lo' terms -- what csrc/gemm_h2p.hip streams for both operands.  None when a value
+    does not fit fp16's range."""
+    n, k = t.shape
+    if k % 32 or not bool(torch.isfinite(t).all()) or float(t.abs().max()) >= 65504.0:
+        return None
+    planes = split_f16x2(t.float())
+    return planes.view(2, n, k // 32, 32).permute(1, 2, 0, 3).contiguous().reshape(-1)
+
+
+def unpack_f16x2_k32(buf, n, k):
+    """Inverse of the H2K32 layout (tests): (hi, lo') fp16 tensors [n][k] of a buffer holding n rows of k elements."""
+    v = buf.view(torch.float16).reshape(n, k // 32, 2, 32)
+    return v[:, :, 0, :].reshape(n, k), v[:, :, 1, :].reshape(n, k)
+
+
 def pack_mxfp8(t):
     """The prec-3 weight buffer of lvae_gemm_f32 for an [N][K] fp32 weight: OCP MX-fp8 -- e4m3 elements with one E8M0
     (power-of-two) scale per 32 consecutive k of a row -- as a uint8 tensor: [N][Kp] element bytes followed by [N][Kp/32] scale
@@ -104,7 +121,8 @@ class LazyW16:
             h = self.map.get(ptr)
             if h is None:
                 c = (pack_bf16x3(t) if self.mode == 'bf16x3' else pack_mxfp8(t) if self.mode == 'mxfp8'
-                     else pack_f16x2(t) if self.mode == 'f16x2' else t.to(torch.bfloat16).contiguous())
+                     else pack_f16x2(t) if self.mode == 'f16x2' else pack_f16x2_k32(t) if self.mode == 'f16x2k32'
+                     else t.to(torch.bfloat16).contiguous())
                 if c is None:                       # f16x2: a weight outside fp16's range
                     self.map[ptr] = 0
                     return None
@@ -128,6 +146,11 @@ def f16x2_weight_map(tensors):
     return m, m.keep
 
 
+def f16x2k32_weight_map(tensors):
+    m = LazyW16(tensors, 'f16x2k32')
+    return m, m.keep
+
+
 def mxfp8_weight_map(tensors):
     m = LazyW16(tensors, 'mxfp8')
     return m, m.keep
@@ -137,7 +160,7 @@ def mxfp8_weight_map(tensors):
 # for bit) and the container -- the reference's, byte for byte -- does not record it: the default is FIXED here (no environment
 # override), another mode is an explicit `model.set_gemm_precision(...)` call that must be made identically on both sides
 # (DESIGN.md 4).  compress_mode() logs the active mode once per model.
-DEFAULT_PRECISION = 'bf16x3'
+DEFAULT_PRECISION = 'f16x2'
 PRECISIONS = ('fp32', 'bf16', 'bf16x3', 'f16x2', 'fp8')
 PREC_CODE = {'fp32': 0, 'bf16': 1, 'bf16x3': 2, 'fp8': 3, 'f16x2': 4}        # lvae_gemm_desc.prec
 assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION

@@ -241,12 +241,13 @@ class _Packed:
     def bf16_map(self, mode):
         """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
         builder would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, _W16_LOCK
+        from ..base import bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, f16x2k32_weight_map, _W16_LOCK
         with _W16_LOCK:
             if not hasattr(self, '_w16'):
                 self._w16 = {}
             if mode not in self._w16:
-                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'f16x2': f16x2_weight_map}[mode](self.t)
+                self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'f16x2': f16x2_weight_map,
+                                   'f16x2k32': f16x2k32_weight_map}[mode](self.t)
         return self._w16[mode][0]
 
 
@@ -259,6 +260,7 @@ class _QresPlan(Plan):
         self.prec = PREC_CODE[model._prec]
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
+        self.w16_k32 = pk.bf16_map('f16x2k32') if self.prec == 4 else None
         self.lat_shapes, self.idx_off, self.sym_off, self.cuts = [], [], [], []
         self.qcuts, self.prm_bufs, self.qm_bufs, self.zhat_bufs, self.zhat_ld = [], [], [], [], []   # test access (CodecBase._trace_blocks)
         nH, nW = H // 64, W // 64
@@ -400,12 +402,14 @@ class _QresPlan(Plan):
         C, k, hid = m.dim, m.kernel_size, m.hidden
         M = self.B * H * W
         y, hbuf = self.buf('y', M * C), self.buf('hid', M * hid)
-        self.add(lib.lvae_dwconv_ln_f32, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), pk.p(p + '.ln_w'), pk.p(p + '.ln_b'), None, None,
-                                          y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
+        h2p = self.mlp_h2p_ok(C, hid, k, rows_per_image=H * W)            # f16x2 plans: pre-split y / hidden map (see the qarv plan's cnx)
+        self.add(lib.lvae_dwconv_ln_h2 if h2p else lib.lvae_dwconv_ln_f32,
+                 (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), pk.p(p + '.ln_w'), pk.p(p + '.ln_b'), None, None,
+                  y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
         self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=hbuf.data_ptr(),
-                  epi=_native.EPI_BIAS_GELU, label=p + '.fc1')
+                  epi=_native.EPI_BIAS_GELU, a_h2=h2p, out_h2=h2p, label=p + '.fc1')
         self.gemm(A0=hbuf.data_ptr(), K0=hid, M=M, N=C, Wt=pk.p(p + '.fc2_w'), bias=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'),
-                  res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, label=p + '.fc2')
+                  res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, a_h2=h2p, label=p + '.fc2')
 
     def vdblock(self, p, m, a0, a1, out, H, W):
         """c4(g(c3(g(c2(g(c1(g(x)))))))) with x = a0 or cat[a0, a1] (each of width cin or cin/2)."""

@@ -11,17 +11,18 @@ never the cascade of an earlier flip.  Then, per latent block:
   * index flips: |i - i_ref| == 1 and both sigmas within IDX_BAND (relative) of the table threshold between the two indexes;
   * symbol flips: |s - s_ref| == 1 and both (qm - pm) within SYM_BAND of the half-integer between the two symbols.
 
-The bands are a few times the rounding noise measured on the MI355X (rms deviation 3e-6, max 6e-5 at 512x768 with the
-'wide' seeded weights whose pre-round values reach +-400) and 10^3..10^4 times smaller than the quantisation step they guard.
+The bands are 3-10x the rounding noise measured on the MI355X at 512x768 (2.1 M teacher-forced elements of qres34m and of a batch-of-8
+qarv_base encode, 'wide' seeded weights: every element within 3.4e-5 / 1.3e-5 in ln sigma; the 22 flips within 1.3e-5 of their
+half-integer / 3.0e-6 relative of their table threshold) and 10^3..10^4 times smaller than the quantisation step they guard.
 """
 import math
 
 import numpy as np
 
-VAL_ATOL, VAL_RTOL = 1.5e-4, 2e-5     # pm, qm (values up to a few hundred with the 'wide' seeded weights)
-LNS_TOL = 1e-4                        # ln sigma
-IDX_BAND = 1e-4                       # |sigma / threshold - 1| of a flipped scale index, on both sides
-SYM_BAND = 2e-4                       # | |qm - pm| - (k + 1/2) | of a flipped symbol, on both sides (absolute, + VAL_RTOL * |qm - pm|)
+VAL_ATOL, VAL_RTOL = 1e-4, 2e-5       # pm, qm (values up to a few hundred with the 'wide' seeded weights); measured max 3.4e-5
+LNS_TOL = 5e-5                        # ln sigma; measured max 1.3e-5
+IDX_BAND = 3e-5                       # |sigma / threshold - 1| of a flipped scale index, on both sides; measured worst 3.0e-6
+SYM_BAND = 1e-4                       # | |qm - pm| - (k + 1/2) | of a flipped symbol, on both sides (+ VAL_RTOL * |qm - pm|); measured worst 1.3e-5
 
 
 def sigma_from_lv(lv, bound):

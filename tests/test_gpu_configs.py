@@ -152,7 +152,9 @@ def test_config3_qres34m_512x768_against_oracle():
     assert n == guard['n'] == 1536 + 2 * 5376 + 3 * 18432 + 3 * 61440 + 3 * 196608       # symbols per block, 512x768
     assert err <= 1e-4, err
     assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
-    assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
+    # free-running: only the flips up to the first symbol flip are independent events; what follows is the cascade of a changed latent
+    # (recorded, not bounded: one early flip legitimately changes every later prior)
+    assert f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
     obj = m.compress(im.cuda())
     assert torch.equal(m.decompress(obj), m.decompress(m.compress(im.cuda())))
 
@@ -191,7 +193,7 @@ def test_config2_qarv_base_b8_512x768_against_oracle():
     assert n == guard['n'] == 2 * 617472                 # symbols per 512x768 image
     assert err <= 1e-4, err
     assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
-    assert flips + iflips <= 2e-3 * n, (flips, iflips, n)
+    assert f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)          # free-running: first-order flips only (see the qres34m test)
     # the batched strings are what single-image calls give, and the round trip is deterministic
     strings = m.compress_batch(ims.cuda(), lmb)
     assert strings[5] == m.compress(ims[5:6].cuda(), lmb)

@@ -176,3 +176,68 @@ def test_gemm_f16x2_rejects_what_it_does_not_take():
     assert pack_f16x2(torch.full((4, 32), 1e5)) is None               # beyond fp16's range: the host keeps such a GEMM on bf16x3
     out = torch.empty(64, 32, device='cuda')
     assert _gemm(A, 48, 48, Wt, pack_f16x2(Wt), None, out, 32, 64) == -22      # K % 32 != 0
+
+
+# ---------------------------------------------------------------------------------------------- pre-split operands (csrc/gemm_h2p.hip)
+@pytest.mark.parametrize('tile', [42, 41, 22, 21, 0])
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 384, 192, 1), (256, 128, 32, 0), (3001, 192, 384, 2), (520, 448, 256, 1), (12288, 768, 384, 1),
+                                       (777, 64, 1536, 2)])
+def test_gemm_h2p_equals_h2_bit_for_bit(M, N, K, epi, tile):
+    """Both operands pre-split (H2K32 planes, LDS-DMA main loop) against gemm_h2_kernel on the fp32 operand: same split, same
+    per-accumulator MFMA sequence => every output bit equal, for every tile shape (ragged M / N included)."""
+    from lvae.models.base import pack_f16x2, pack_f16x2_k32
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    ref = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, pack_f16x2(Wt), bias, ref, N, M, epi, gamma=gamma, res=res) == 0
+    out = torch.full((M, N), float('nan'), device='cuda')
+    Ah = pack_f16x2_k32(A)
+    assert _gemm(Ah, K, K, Wt, pack_f16x2_k32(Wt), bias, out, N, M, epi, gamma=gamma, res=res, a_h2=1, cfg=tile) == 0
+    assert not torch.isnan(ref).any() and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('a_h2', [0, 1])
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 384, 192, 1), (300, 64, 64, 0), (4100, 768, 384, 1)])
+def test_gemm_out_h2_is_the_split_of_the_fp32_result(M, N, K, epi, a_h2):
+    """out_h2: the stored planes are exactly split_f16x2 of what the same GEMM stores as fp32 (fc1's hidden map for fc2)."""
+    from lvae.models.base import pack_f16x2, pack_f16x2_k32, split_f16x2, unpack_f16x2_k32
+    g = torch.Generator().manual_seed(M + N + K + 3)
+    A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Ain, Wp = (pack_f16x2_k32(A), pack_f16x2_k32(Wt)) if a_h2 else (A, pack_f16x2(Wt))
+    ref = torch.empty(M, N, device='cuda')
+    assert _gemm(Ain, K, K, Wt, Wp, bias, ref, N, M, epi, a_h2=a_h2) == 0
+    out = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(Ain, K, K, Wt, Wp, bias, out, N, M, epi, a_h2=a_h2, out_h2=1) == 0
+    hi, lo = unpack_f16x2_k32(out, M, N)
+    want = split_f16x2(ref)
+    assert torch.equal(hi, want[0]) and torch.equal(lo, want[1])
+
+
+@pytest.mark.parametrize('B,H,W,C,k,affine', [(2, 16, 24, 192, 7, 'adaln'), (1, 9, 13, 128, 7, 'adaln'), (3, 8, 8, 512, 3, 'adaln'),
+                                               (2, 12, 20, 384, 5, 'ln'), (1, 4, 6, 512, 1, 'adaln'), (2, 33, 17, 256, 7, 'none')])
+def test_dwconv_ln_h2_is_the_split_of_the_fp32_result(B, H, W, C, k, affine):
+    """lvae_dwconv_ln_h2 (depthwise + LayerNorm + affine, result stored pre-split for fc1) == split_f16x2 of lvae_dwconv_ln_f32."""
+    from lvae import _native
+    from lvae.models.base import split_f16x2, unpack_f16x2_k32
+    L = _native.lib()
+    g = torch.Generator().manual_seed(B + H + W + C + k)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    wt = (torch.randn(k * k, C, generator=g) / k).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    a0, a1 = torch.randn(C, generator=g).cuda(), (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+    ln = (a1.data_ptr(), a0.data_ptr()) if affine == 'ln' else (None, None)
+    ada = (a0.data_ptr(), a1.data_ptr()) if affine == 'adaln' else (None, None)
+    y = torch.empty_like(x)
+    assert L.lvae_dwconv_ln_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), *ln, *ada, y.data_ptr(), B, H, W, C, k, _st()) == 0
+    y2 = torch.full_like(x, float('nan'))
+    assert L.lvae_dwconv_ln_h2(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), *ln, *ada, y2.data_ptr(), B, H, W, C, k, _st()) == 0
+    torch.cuda.synchronize()
+    hi, lo = unpack_f16x2_k32(y2, B * H * W, C)
+    want = split_f16x2(y.view(-1, C))
+    assert torch.equal(hi, want[0]) and torch.equal(lo, want[1])
+    assert L.lvae_dwconv_ln_h2(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), None, None, None, None, y2.data_ptr(), B, H, W, 144, k, _st()) == -22

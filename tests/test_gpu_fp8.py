@@ -216,8 +216,8 @@ def test_config5_tecnick_1216x1216_fp8_mode(typical_model):
                        for i in range(4)]).cuda()
     assert ims.shape == (4, 3, 1216, 1216)
     lmb = 512.0
+    base = m._prec                                                  # the package's fp32-class default arithmetic
     try:
-        m.set_gemm_precision('bf16x3')
         s_ref = m.compress_batch(ims, lmb)
         x_ref = m.decompress_batch(s_ref)
         m.set_gemm_precision('fp8')
@@ -234,19 +234,23 @@ def test_config5_tecnick_1216x1216_fp8_mode(typical_model):
         print(f'config 5: PSNR fp32-class {p_ref:.3f} dB, fp8 mode {p8:.3f} dB; bpp {b_ref:.4f} vs {b8:.4f}; '
               f'PSNR(fp8 recon vs fp32-class recon) {_psnr(x8, x_ref):.2f} dB')
         assert abs(p8 - p_ref) <= 0.5 and abs(b8 - b_ref) <= 0.05 * b_ref
+        # the informative figure on random weights: how far the mode's reconstruction is from the fp32-class one (its own noise
+        # floor; 37.7 dB measured in round 2) -- asserted, and tracked per lambda by test_config5_mode_noise_per_lambda
+        assert _psnr(x8, x_ref) >= 37.0, _psnr(x8, x_ref)
         # a stream of one mode must not be decoded in another one: the arithmetic is part of the stream's contract
-        m.set_gemm_precision('bf16x3')
+        m.set_gemm_precision(base)
         try:
             bad = m.decompress_batch(s8)
             assert not torch.equal(bad, x8)
         except (ValueError, RuntimeError):
             pass
     finally:
-        m.set_gemm_precision('bf16x3')
+        m.set_gemm_precision(base)
 
 
 def test_fp8_mode_small_images_and_estimate(typical_model):
     m = typical_model
+    base = m._prec
     try:
         m.set_gemm_precision('fp8')
         im = torch.from_numpy(seeded_init.synthetic_image_u8(128, 192, 3)).permute(2, 0, 1).float().div(255).unsqueeze(0).cuda()
@@ -258,4 +262,27 @@ def test_fp8_mode_small_images_and_estimate(typical_model):
             bits = float(nats.sum()) / math.log(2)
             assert 0.6 * bits < len(s) * 8 < 1.1 * bits + 800
     finally:
-        m.set_gemm_precision('bf16x3')
+        m.set_gemm_precision(base)
+
+
+def test_config5_mode_noise_per_lambda(typical_model):
+    """PSNR(fp8-mode reconstruction, fp32-class reconstruction) at lambda = 16 / 256 / 2048 on a 1216x1216 image: the mode's own noise
+    floor, the figure that decides whether config 5 is usable at a trained model's 44 dB (unknown until real weights are measured;
+    scripts/accept-published.py reports it when a checkpoint is present).  Recorded in the log, asserted >= 35 dB."""
+    from lvae.utils.coding import pad_divisible_by, pil_to_tensor01
+    from PIL import Image
+    m = typical_model
+    im = pil_to_tensor01(pad_divisible_by(Image.fromarray(seeded_init.synthetic_image_u8(1200, 1200, 950)), 64)).unsqueeze(0).cuda()
+    base = m._prec
+    rows = []
+    try:
+        for lmb in (16.0, 256.0, 2048.0):
+            m.set_gemm_precision(base)
+            x_ref = m.decompress(m.compress(im, lmb))
+            m.set_gemm_precision('fp8')
+            x8 = m.decompress(m.compress(im, lmb))
+            rows.append((lmb, _psnr(x8, x_ref), _psnr(x_ref, im), _psnr(x8, im)))
+    finally:
+        m.set_gemm_precision(base)
+    print('config 5 noise floor: ' + '; '.join(f'lambda {l:g}: recon-vs-recon {a:.2f} dB (vs image: {b:.3f} / {c:.3f} dB)' for l, a, b, c in rows))
+    assert all(a >= 35.0 for _, a, _, _ in rows), rows

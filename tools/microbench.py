@@ -49,6 +49,13 @@ def bench_gemm(M, N, K, epi):
         w16 = pack_bf16x3(Wt) if prec == 2 else pack_f16x2(Wt) if prec == 4 else Wt.to(torch.bfloat16).contiguous()
         d.Wt16, d.prec = w16.data_ptr(), prec
         d._keep = w16
+        if prec == 4 and os.environ.get('LVAE_H2P'):       # both operands pre-split (csrc/gemm_h2p.hip); LVAE_H2P = tile (42 41 22 21) or 1
+            from lvae.models.base import pack_f16x2_k32
+            ah, wh = pack_f16x2_k32(A), pack_f16x2_k32(Wt)
+            d.A0, d.Wt16, d.a_h2 = ah.data_ptr(), wh.data_ptr(), 1
+            d.cfg = int(os.environ['LVAE_H2P']) if int(os.environ['LVAE_H2P']) > 1 else 0
+            d.out_h2 = int(os.environ.get('LVAE_OUT_H2', '0')) if epi in (0, 1) else 0
+            d._keep = (ah, wh)
     t = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(d), st()))
     return t
 
