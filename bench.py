@@ -201,7 +201,14 @@ def main():
     # one rank per GPU shares the node's host cores: every rank's threads (launch threads, rANS coder pool) stay on its slice of
     # the cores of its GPU's NUMA node (skipped when the node topology cannot be read or looks skewed), pool sized to the slice
     ncpu = None
-    if world > 1 and os.environ.get('LVAE_BENCH_SINGLE_GPU_TEST') != '1':
+    if world > 1 and os.environ.get('LVAE_BENCH_REHEARSE_HOST') == '1':
+        # rehearsal of the N-rank HOST load on a 1-GPU box (tools/host_contention.sh): every rank gets its own 1/N slice of the cores
+        # the job may use -- what NUMA pinning gives it on the real node -- although all ranks share cuda:0
+        allowed = sorted(os.sched_getaffinity(0))
+        per = max(1, len(allowed) // world)
+        os.sched_setaffinity(0, allowed[rank * per:(rank + 1) * per])
+        ncpu = per
+    elif world > 1 and os.environ.get('LVAE_BENCH_SINGLE_GPU_TEST') != '1':
         try:
             from lvae.utils.numa import pin_ranks_collectively
             ncpu = pin_ranks_collectively(local_rank, dist, local_rank, world)
@@ -211,7 +218,7 @@ def main():
     if ncpu:
         model.coder_threads = max(4, ncpu)
     else:
-        model.coder_threads = max(8, (os.cpu_count() or 64) // max(1, world))
+        model.coder_threads = max(8, len(os.sched_getaffinity(0)) // max(1, world))      # the cores this process may use, not the machine's
     model.set_gemm_precision(args.precision)
     ims = synth_batch(B, H, W, rank).to(dev)
 
@@ -384,8 +391,9 @@ def main():
         except Exception as e:                           # diagnostic only: never lose the bench line over it
             coder = {'error': repr(e)}
 
-    if rank == 0 and model.timing is not None:
-        print('host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()}, file=sys.stderr)
+    if model.timing is not None and (rank == 0 or os.environ.get('LVAE_BENCH_REHEARSE_HOST') == '1'):
+        print(f'[rank {rank}] host phase timers (s, all steps incl. warm-up):', {k: round(v, 4) for k, v in model.timing.items()},
+              f'coder_threads={model.coder_threads}', file=sys.stderr, flush=True)
     if rank == 0:
         px = world * B * H * W * args.steps
         line = {

@@ -244,7 +244,7 @@ class CodecBase(nn.Module):
     def _coder_threads_per_group(self, n_groups):
         if n_groups == 1:
             return self.coder_threads
-        return max(1, (self.coder_threads or (os.cpu_count() or 8)) // n_groups)
+        return max(1, (self.coder_threads or len(os.sched_getaffinity(0))) // n_groups)
 
     def _groups(self, B, kind=None):
         """Split a batch of B into contiguous groups [(start, size)] for the stream/thread pipeline."""
