@@ -159,6 +159,19 @@ typedef struct {
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
 
+/* Native replay of a recorded launch-plan segment (csrc/plan_runtime.cpp; lvae/engine.py: Plan.run): ONE foreign call instead of one
+ * per launch.  Every entry names an entry point of this header (`kind`) and carries its arguments by class in call order: pointers in
+ * p[], integers (int / long) in i[], floats in f[]; the stream argument comes from the call (`side` != 0: the side stream).
+ * LVAE_OP_ORDER: p[0] = event, i[0] != 0: side stream waits for main (fork), else main waits for side (join).
+ * Returns 0, or the first failing launch's code with its index in *failed_index (may be NULL). */
+enum {
+    LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
+    LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
+    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_ORDER
+};
+typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
+int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int* failed_index);
+
 /* Depthwise kxk conv (+bias) -> LayerNorm over C (eps 1e-6, biased variance, no affine) -> AdaLN
  * y*(1+scale)+shift, one pass over an NHWC map (common.py:145-152).  wt is [k*k][C] (tap-major), `ln_w`/`ln_b`
  * (optional, may be NULL) are the LayerNorm affine of qres34m's MyConvNeXtBlock (qresvae/model.py:168-182);

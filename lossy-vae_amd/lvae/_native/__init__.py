@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 
@@ -29,6 +29,18 @@ class GemmDesc(C.Structure):
         ('a_h2', C.c_int), ('out_h2', C.c_int),
     ]
 
+
+class Op(C.Structure):
+    """Mirror of `lvae_op` (include/lvae_hip.h): one entry of a native launch-plan segment (lvae_run_ops)."""
+    _fields_ = [('kind', C.c_int), ('side', C.c_int), ('p', C.c_void_p * 8), ('i', C.c_long * 6), ('f', C.c_double * 2)]
+
+
+# lvae_op.kind of every entry point a launch plan may hold (enum LVAE_OP_* of the header, in its order)
+OP_KINDS = {name: k + 1 for k, name in enumerate([
+    'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_stem_f32', 'lvae_stem_bf16',
+    'lvae_bias_expand_f32', 'lvae_bias_expand_bf16', 'lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32',
+    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32'])}
+OP_ORDER = len(OP_KINDS) + 1
 
 A_PLAIN, A_PATCH2, A_CONV3 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_GAMMA_RES, EPI_RES = 0, 1, 2, 3
@@ -67,6 +79,7 @@ SIGNATURES = {
     'lvae_event_create': (_vp, []),
     'lvae_event_destroy': (_i, [_vp]),
     'lvae_stream_order': (_i, [_vp, _vp, _vp]),
+    'lvae_run_ops': (_i, [_vp, _i, _vp, _vp, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'lvae_sqerr_partials_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
 }
@@ -84,6 +97,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+            fn.lvae_name = name
         v = L.lvae_abi_version()
         if v != ABI_VERSION:
             raise RuntimeError(f'liblvae_hip.so ABI {v} != expected {ABI_VERSION}; rebuild')

@@ -133,6 +133,7 @@ class Plan:
         self.w16_x3 = None     # f16x2 plans: the bf16x3 map for the GEMMs the f16x2 kernel does not take
         self.w16_k32 = None    # f16x2 plans: weights in the H2K32 plane format for the pre-split-operand GEMMs (csrc/gemm_h2p.hip)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
+        self.segments = {}     # (lo, hi, n_ops) -> (lvae_op array, n): the native form of that launch range
         self.seen = set()
         # Independent branches on a side stream (small maps only: there the GPU is far from full and the launches of a branch are
         # pure latency): ops recorded between side_begin() / side_end() go to `side_stream`, ordered against the main stream by
@@ -297,7 +298,48 @@ class Plan:
     # conflicts with the two pipeline-group threads launching concurrently (hipErrorStreamCaptureInvalidated).
     use_graphs = os.environ.get('LVAE_GRAPHS', '0') == '1'
 
+    # Replay: a launch range is compiled once into a native segment (an array of lvae_op: entry point id + arguments by class) and run
+    # by ONE foreign call that needs no interpreter state (csrc/plan_runtime.cpp) -- with several pipeline groups launching from their
+    # own threads, one ctypes call per launch made the interpreter lock the schedule.  LVAE_PY_REPLAY=1 keeps the per-launch Python
+    # loop (debugging: the failing launch's label comes with the error either way).
+    py_replay = os.environ.get('LVAE_PY_REPLAY', '0') == '1'
+
+    def _segment(self, lo, hi):
+        key = (lo, hi, len(self.ops))
+        seg = self.segments.get(key)
+        if seg is None:
+            ops = self.ops[lo:hi]
+            arr = (_native.Op * max(1, len(ops)))()
+            for o, (fn, args, label, side) in zip(arr, ops):
+                o.side = int(bool(side))
+                if fn is _ORDER:
+                    o.kind, o.p[0], o.i[0] = _native.OP_ORDER, args[1], int(bool(args[0]))
+                    continue
+                o.kind = _native.OP_KINDS[fn.__name__]
+                np_, ni, nf = 0, 0, 0
+                for a, t in zip(args, fn.argtypes[:-1]):
+                    if t in (ctypes.c_float, ctypes.c_double):
+                        o.f[nf] = float(a); nf += 1
+                    elif t in (ctypes.c_int, ctypes.c_long):
+                        o.i[ni] = int(a); ni += 1
+                    else:                                   # pointer: None, an address, or a byref() of a kept descriptor
+                        o.p[np_] = a if (a is None or isinstance(a, int)) else ctypes.cast(a, ctypes.c_void_p).value
+                        np_ += 1
+            seg = self.segments[key] = (arr, len(ops))
+        return seg
+
+    def _run_native(self, lo, hi, s):
+        arr, n = self._segment(lo, len(self.ops) if hi is None else hi)
+        bad = ctypes.c_int(-1)
+        ss = self.side_stream.cuda_stream if self.side_stream is not None else None
+        rc = self.lib.lvae_run_ops(arr, n, ctypes.c_void_p(s), ctypes.c_void_p(ss) if ss is not None else None, ctypes.byref(bad))
+        if rc != 0:
+            label = self.ops[lo + bad.value][2] if bad.value >= 0 else '?'
+            raise RuntimeError(f'native launch "{label}" failed: rc={rc}')
+
     def _run_eager(self, lo, hi, s):
+        if not self.py_replay:
+            return self._run_native(lo, hi, s)
         sp = ctypes.c_void_p(s)
         ss = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else None
         for fn, args, label, side in self.ops[lo:hi]:
