@@ -195,9 +195,12 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
         attr_set = true;
     }
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
+    static int lds_pad = -1;             // experiment knob: extra dynamic LDS (forces one 128-row workgroup per CU)
+    if (lds_pad < 0) { const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0; }
+    if (lds_pad > 0) hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
     static int stagger = -1;             // experiment knob (default off: measured 0 ... -5 % on the model's shapes)
     if (stagger < 0) { const char* e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS, st, *d, tiles_n, n_tiles, stagger);
+    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
     return (int)hipGetLastError();
 }
 

@@ -375,3 +375,31 @@ def test_prior_sampling_statistics_and_determinism(product_model):
     assert L.lvae_prior_sample_f32(prm.data_ptr(), out0.data_ptr(), M, z, z + 2, 0.0, 99, 0, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(out0[:, :z], prm[:, :z]) and float(out0[:, z:].abs().max()) == 0.0
+
+
+def test_encode_is_stable_under_stream_concurrency(product_model):
+    """Byte-compare stress: kernels of two HIP streams share the CUs in two situations -- the opt-in side stream of small
+    encode plans (posterior0 / prior head beside the main branch) and the two pipeline groups of a batch.  Encoding the same input over
+    and over must give the same bytes every time, the same as with the side stream off, and batch == single."""
+    m = product_model
+    im = _img(512, 768, 5).cuda()
+    ref = m.compress(im, 700.0)
+    m.side_streams = True
+    try:
+        outs = {m.compress(im, 700.0) for _ in range(40)}
+        assert outs == {ref}, f'{len(outs)} different bitstreams with the side stream on'
+        small = _img(128, 192, 6).cuda()
+        m.side_streams = False
+        ref_small = m.compress(small, 64.0)
+        m.side_streams = True
+        assert {m.compress(small, 64.0) for _ in range(60)} == {ref_small}
+    finally:
+        m.side_streams = False
+    ims = torch.cat([_img(256, 384, 400 + i) for i in range(8)], 0).cuda()
+    first = m.compress_batch(ims, 300.0)
+    for _ in range(15):
+        assert m.compress_batch(ims, 300.0) == first
+    assert first[3] == m.compress(ims[3:4], 300.0)
+    x = m.decompress_batch(first)
+    for _ in range(5):
+        assert torch.equal(m.decompress_batch(first), x)
