@@ -96,7 +96,18 @@ __global__ __launch_bounds__(256, (TN == 1 ? 3 : 2)) void gemm_h2_kernel(const l
             }
         }
     }
-    const int a_all_rec = (AMODE == LVAE_A_CONV3) ? (int)((long)d.M * d.K0 * 4) : 0;
+    // 2x2 / stride-2 patch gather (patch_downsample, common.py:29-30; K = 4*Cin ordered (i, j, ci)): output row m = (bh, w) reads the
+    // input pixels (2 bh + i, 2 w + j); the two pixels of one i are adjacent in NHWC, so k -> i = k / (2 Cin) selects a uniform row
+    // offset and the rest is contiguous.  A stage of 16 channels lies inside one i (Cin % 8 == 0).
+    if (AMODE == LVAE_A_PATCH2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 256 * j, m = m0 + perm(c >> 2), ak4 = c & 3;
+            const int w = m % d.W, bh = m / d.W;
+            a_voff[j] = m < d.M ? (int)((((long)bh * 2 * (2L * d.W) + 2L * w) * d.K0 + ak4 * 4) * 4) : 0x7fffffff;
+        }
+    }
+    const int a_all_rec = (AMODE == LVAE_A_CONV3) ? (int)((long)d.M * d.K0 * 4) : (AMODE == LVAE_A_PATCH2) ? (int)((long)d.M * 4 * d.K0 * 4) : 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int c = tid + 256 * j, row = perm(c >> 2), piece = c & 3;
@@ -129,6 +140,14 @@ __global__ __launch_bounds__(256, (TN == 1 ? 3 : 2)) void gemm_h2_kernel(const l
             int vo = a_voff[j] + toff;
             vo = ((tapok[j] >> tap) & 1) ? vo : 0x7fffffff;
             ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            return;
+        }
+        if (AMODE == LVAE_A_PATCH2) {
+            const int kq = qg * 16, seg = 2 * d.K0, i = kq / seg, kk = kq - i * seg;     // uniform
+            int toff = (i * 2 * d.W * d.K0 + kk) * 4;
+            asm volatile("" : "+s"(toff));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.A0, 0, a_all_rec, 0x00020000);
+            ra[par][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff[j], toff, 0);
             return;
         }
         const bool second = qg >= qsplit;
@@ -249,11 +268,13 @@ int launch_h2(const lvae_gemm_desc* d, hipStream_t st) {
 // otherwise -- the host (lvae/engine.py: h2_eligible) only asks for prec 4 where it is, so 0 is an argument error upstream.
 // force: 0 = choose the tile width; 1..2 = TN (tuning hook LVAE_H2_TN).  Every choice gives the same bits.
 int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
-    const bool conv3 = d->a_mode == LVAE_A_CONV3;
-    if (d->prec != 4 || (d->a_mode != LVAE_A_PLAIN && !conv3) || (d->K & 31) || d->ldw != d->K) return 0;
-    if (!conv3 && ((d->lda0 & 3) || d->K0 + d->K1 != d->K)) return 0;
+    const bool conv3 = d->a_mode == LVAE_A_CONV3, patch2 = d->a_mode == LVAE_A_PATCH2;
+    if (d->prec != 4 || (d->a_mode != LVAE_A_PLAIN && !conv3 && !patch2) || (d->K & 31) || d->ldw != d->K) return 0;
+    if (patch2 && ((d->K0 & 7) || d->K != 4 * d->K0 || d->K1 != 0 || d->H <= 0 || d->W <= 0 || d->a_gelu || (long)d->M * 4 * d->K0 * 4 > 0x7ffffff0L))
+        return 0;
+    if (!conv3 && !patch2 && ((d->lda0 & 3) || d->K0 + d->K1 != d->K)) return 0;
     if (conv3 && ((d->K0 & 15) || d->K != 9 * d->K0 || d->K1 != 0 || d->H <= 0 || d->W <= 0 || (long)d->M * d->K0 * 4 > 0x7ffffff0L)) return 0;
-    const bool cat = d->K1 != 0;
+    const bool cat = d->K1 != 0 && !patch2;
     if (cat && (!d->A1 || (d->K0 & 15) || (d->lda1 & 3) || (long)256 * d->lda1 * 4 > 0x7fffffffL)) return 0;
     if ((long)128 * d->lda0 * 4 > 0x7fffffffL || (long)192 * 4 * d->K > 0x7fffffffL) return 0;
     const int S = d->ksplit > 1 ? d->ksplit : 1;
@@ -272,7 +293,8 @@ int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc
         }
     }
 #define LVAE_H2_LAUNCH(G, AM) (sel == 1 ? launch_h2<1, G, AM>(d, st) : launch_h2<2, G, AM>(d, st))
-    if (conv3) *rc = d->a_gelu ? LVAE_H2_LAUNCH(true, LVAE_A_CONV3) : LVAE_H2_LAUNCH(false, LVAE_A_CONV3);
+    if (patch2) *rc = LVAE_H2_LAUNCH(false, LVAE_A_PATCH2);
+    else if (conv3) *rc = d->a_gelu ? LVAE_H2_LAUNCH(true, LVAE_A_CONV3) : LVAE_H2_LAUNCH(false, LVAE_A_CONV3);
     else *rc = d->a_gelu ? LVAE_H2_LAUNCH(true, LVAE_A_PLAIN) : LVAE_H2_LAUNCH(false, LVAE_A_PLAIN);
 #undef LVAE_H2_LAUNCH
     return 1;

@@ -97,6 +97,8 @@ def h2_eligible(d):
         return True
     if d.a_mode == _native.A_CONV3:
         return d.K0 % 16 == 0 and d.K == 9 * d.K0 and d.K1 == 0 and d.H > 0 and d.W > 0 and d.M * d.K0 * 4 <= 0x7ffffff0
+    if d.a_mode == _native.A_PATCH2:
+        return d.K0 % 8 == 0 and d.K == 4 * d.K0 and d.K1 == 0 and d.H > 0 and d.W > 0 and not d.a_gelu and d.M * 16 * d.K0 <= 0x7ffffff0
     return False
 
 

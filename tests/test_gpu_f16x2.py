@@ -241,3 +241,24 @@ def test_dwconv_ln_h2_is_the_split_of_the_fp32_result(B, H, W, C, k, affine):
     want = split_f16x2(y.view(-1, C))
     assert torch.equal(hi, want[0]) and torch.equal(lo, want[1])
     assert L.lvae_dwconv_ln_h2(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), None, None, None, None, y2.data_ptr(), B, H, W, 144, k, _st()) == -22
+
+
+@pytest.mark.parametrize('B,Ho,Wo,Cin,Cout', [(2, 6, 10, 192, 384), (1, 3, 5, 512, 512), (3, 1, 1, 384, 512), (2, 16, 24, 384, 512), (1, 7, 9, 8, 64)])
+def test_gemm_f16x2_patch2_gather(B, Ho, Wo, Cin, Cout):
+    """2x2 / stride-2 patch gather (patch_downsample, common.py:29-30) on the f16x2 kernel against F.conv2d in fp64, and image b of the
+    batch == the same image alone."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, 2 * Ho, 2 * Wo, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 2, 2, generator=g) / (4 * Cin) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    Wt = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    M, K = B * Ho * Wo, 4 * Cin
+    out = torch.full((M, Cout), float('nan'), device='cuda')
+    assert _gemm(xn, Cin, Cin, Wt, pack_f16x2(Wt), bias, out, Cout, M, a_mode=1, H=Ho, W=Wo, K=K) == 0
+    assert float((out.double() - ref).abs().max()) < 2e-5
+    one = torch.empty(Ho * Wo, Cout, device='cuda')
+    assert _gemm(xn[B - 1].contiguous(), Cin, Cin, Wt, pack_f16x2(Wt), bias, one, Cout, Ho * Wo, a_mode=1, H=Ho, W=Wo, K=K) == 0
+    assert torch.equal(one, out[(B - 1) * Ho * Wo:])
