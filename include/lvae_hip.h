@@ -154,7 +154,12 @@ typedef struct {
                                              streams both operands global -> LDS by DMA with no conversion in its main loop
                                              (csrc/gemm_h2p.hip; Wt16 must be H2K32 as well).  out_h2 = 1: the result (ROWMAJOR,
                                              EPI_BIAS / EPI_BIAS_GELU, N % 32 == 0, ldo = N) is stored split in that format instead
-                                             of fp32.  Same bits as splitting inside the consumer: the split is exact and unique */
+                                             of fp32.  Same bits as splitting inside the consumer: the split is exact and unique.
+                                             prec 3 (reduced-precision mode): the same two flags with the MX-fp8 operand format Q8 of an
+                                             [R][K] matrix (K % 64 == 0): R*K e4m3 bytes row-major, then the E8M0 block scales as
+                                             [K/64][R][2] bytes (lvae.models.base.pack_mxfp8_q8): a_h2 = 1: A0 (and Wt16) are Q8 buffers,
+                                             written by lvae_dwconv_ln_q8 / a GEMM with out_h2 (csrc/gemm_q8.hip: no quantiser in the main
+                                             loop); out_h2 = 1: the result (EPI_BIAS / EPI_BIAS_GELU, N % 64 == 0, ldo = N) is stored as Q8 */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
@@ -165,7 +170,7 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
  * LVAE_OP_ORDER: p[0] = event, i[0] != 0: side stream waits for main (fork), else main waits for side (join).
  * Returns 0, or the first failing launch's code with its index in *failed_index (may be NULL). */
 enum {
-    LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
+    LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_DWCONV_LN_Q8, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
     LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
     LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_ORDER
 };
@@ -187,6 +192,12 @@ int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* bias, const
  * [B*H*W][C/32][2][32] fp16 (B*H*W*C*4 bytes, like the fp32 map); value = split of exactly the fp32 result lvae_dwconv_ln_f32 gives.
  * C in {128,192,256,384,512}, k in {1,3,5,7}, at most one affine (the csrc/dwconv_cl.hip instances); -22 otherwise. */
 int lvae_dwconv_ln_h2(const float* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                      const float* shift, const float* scale1p, void* y,
+                      int B, int H, int W, int C, int k, void* stream);
+
+/* Reduced-precision mode: bf16 map in, result quantised to MX-fp8 (format Q8 of lvae_gemm_desc: [B*H*W][C] e4m3 bytes, then
+ * [C/64][B*H*W][2] E8M0 scales) for the GEMM that consumes it (prec 3, a_h2 = 1).  Same shape rule as lvae_dwconv_ln_h2. */
+int lvae_dwconv_ln_q8(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
                       const float* shift, const float* scale1p, void* y,
                       int B, int H, int W, int C, int k, void* stream);
 

@@ -129,13 +129,17 @@ template <int KS, int NW, int TH, bool BF> constexpr int cl_waves() {
     return by_lds < 1 ? 1 : (by_lds < by_regs ? by_lds : by_regs);
 }
 
-// H2 (fp32 maps only): the result is stored pre-split for the f16x2 GEMM that consumes it (lvae_gemm_desc.a_h2; format H2K32 =
-// [pixel][C/32][2][32] fp16: per 32 channels 32 hi terms, then 32 lo' terms -- 4 bytes per element like fp32) instead of as fp32.
-template <int KS, int NW, int TH, bool BF, bool H2 = false>
+// OF: output format.  0: like the input map (fp32 / bf16).  1 (fp32 maps only): pre-split for the f16x2 GEMM that consumes it
+// (lvae_gemm_desc.a_h2; H2K32 = [pixel][C/32][2][32] fp16: per 32 channels 32 hi terms, then 32 lo' terms -- 4 bytes per element like
+// fp32).  2 (bf16 maps, reduced-precision mode): quantised to MX-fp8 for csrc/gemm_q8.hip (format Q8: [pixel][C] e4m3 bytes, then the
+// E8M0 block scales as [C/64][pixels][2]; `mtot` = number of pixels of the whole batch).
+template <int KS, int NW, int TH, bool BF, int OF = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_waves<KS, NW, TH, BF>(), cl_waves<KS, NW, TH, BF>()))) void dwconv_ln_cl_kernel(
     const void* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ aw,
-    const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy, int tpw) {
+    const float* __restrict__ ab, void* __restrict__ y, int H, int W, int n_sx, int n_sy, int tpw, long mtot) {
     using G = ClGeom<KS, BF>;
+    constexpr bool H2 = OF == 1, Q8 = OF == 2;
+    static_assert(!(H2 && BF) && !(Q8 && !BF), "H2 planes come from fp32 maps, Q8 from bf16 maps");
     constexpr int C = 64 * NW, P = (KS - 1) / 2, SW = CL_SW, XW = G::XW, ES = BF ? 2 : 4, KK = KS * KS, NR = TH + KS - 1;
     constexpr int NG = G::NG, ROWF = G::ROWF, PPI = G::PPI;
     static_assert(XW % 2 == 0, "pixel pairs");
@@ -266,7 +270,38 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
         f32x4 oA, oB;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { oA[e] = fmaf((lnA[e] + sh) * rstd, awA[e], abA[e]); oB[e] = fmaf((lnB[e] + sh) * rstd, awB[e], abB[e]); }
-        if constexpr (H2) {
+        if constexpr (Q8) {
+            // MX-fp8: the 8 lanes of a pixel hold one 32-channel block each in oA (block 2 wave) and oB (block 2 wave + 1): block amax by
+            // DPP, scale = 2^e with amax / 2^e in (224, 448] (the rule of gemm_lp.hip::lp_quant8 / pack_mxfp8), 4 bytes per lane and block
+            auto max8 = [](float m) {
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x141, 0xF, 0xF, true)));
+                return m;
+            };
+            auto quant4 = [&](const f32x4& o, unsigned& eb_out) {
+                const unsigned ab = __float_as_uint(max8(fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])))));
+                int eb = (int)((ab >> 23) & 0xffu) - 8;
+                if ((ab & 0x7fffffu) > 0x600000u) eb += 1;
+                eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+                const float inv = __uint_as_float((unsigned)(254 - eb) << 23);
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * inv, o[1] * inv, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * inv, o[3] * inv, w, true);
+                eb_out = (unsigned)eb;
+                return (unsigned)w;
+            };
+            unsigned eA, eB;
+            const unsigned wA = quant4(oA, eA), wB = quant4(oB, eB);
+            const bool rok = ya >= 0 && ya < H;
+            const long m0r = (b * H + (rok ? ya : 0)) * (long)W;                                   // first pixel of this image row
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)y + m0r * C), 0, rok ? W * C : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)y + mtot * C + ((long)wave * mtot + m0r) * 2), 0,
+                                                                                   rok ? W * 2 : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(wA, rq, xs * C + 64 * wave + 4 * blk, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(wB, rq, xs * C + 64 * wave + 32 + 4 * blk, 0, 0);
+            if (blk == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(eA | (eB << 8)), rsq, xs * 2, 0, 0);
+        } else if constexpr (H2) {
             // this lane's channels chA .. chA + 3 sit at position 4 blk of 32-channel block 2 wave, chB .. + 3 at the same position of
             // block 2 wave + 1; a block is 64 B of hi terms followed by 64 B of lo' terms
             unsigned h0, l0, h1, l1;
@@ -353,25 +388,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
 
 }  // namespace
 // tuning hook LVAE_DW_CL (experimental builds only): 0 = never (earlier forms), 10 * tpw + TH (TH = 1 / 4 / 8) = force, -1 = heuristic
-#if defined(LVAE_CL_BF16_TU) || defined(LVAE_CL_H2_TU)
+#if defined(LVAE_CL_BF16_TU) || defined(LVAE_CL_H2_TU) || defined(LVAE_CL_Q8_TU)
 extern int g_dw_cl;
 #else
 int g_dw_cl = -1;
 #endif
 namespace {
 
-template <int KS, int NW, int TH, bool BF, bool H2>
+template <int KS, int NW, int TH, bool BF, int OF>
 int launch_cl_th(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
                  int tpw, hipStream_t st) {
     const int n_sx = (W + CL_SW - 1) / CL_SW, n_ty = (H + TH - 1) / TH, n_sy = (n_ty + tpw - 1) / tpw;
     const long grid = (long)B * n_sx * n_sy;
     if (grid > 0x7fffffffL || (long)H * W * 64 * NW * (BF ? 2 : 4) > 0x7fffffffL) return -22;
-    hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF, H2>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
-                       n_sx, n_sy, tpw);
+    hipLaunchKernelGGL((dwconv_ln_cl_kernel<KS, NW, TH, BF, OF>), dim3((unsigned)grid), dim3(64 * NW), 0, st, x, wt, bias, aw, ab, y, H, W,
+                       n_sx, n_sy, tpw, (long)B * H * W);
     return (int)hipGetLastError();
 }
 
-template <int KS, int NW, bool BF, bool H2>
+template <int KS, int NW, bool BF, int OF>
 int launch_cl(const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H, int W,
               hipStream_t st) {
     // Output rows per tile (TH) and tiles per workgroup (tpw): the pair with the least estimated time.  A workgroup costs ~3 row
@@ -399,21 +434,21 @@ int launch_cl(const void* x, const float* wt, const float* bias, const float* aw
     int TH = best_th, tpw = best_tpw;
     if (g_dw_cl > 0 && (KS > 1 || g_dw_cl % 10 == 1)) { TH = g_dw_cl % 10; tpw = g_dw_cl / 10 > 0 ? g_dw_cl / 10 : 1; }   // hook: 10 * tpw + TH
     if constexpr (KS > 1) {
-        if (TH == 8) return launch_cl_th<KS, NW, 8, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
-        if (TH >= 2) return launch_cl_th<KS, NW, 4, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH == 8) return launch_cl_th<KS, NW, 8, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+        if (TH >= 2) return launch_cl_th<KS, NW, 4, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
     }
-    return launch_cl_th<KS, NW, 1, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
+    return launch_cl_th<KS, NW, 1, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, tpw, st);
 }
 
-template <int KS, bool BF, bool H2 = false>
+template <int KS, bool BF, int OF = 0>
 int launch_cl_c(int C, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y, int B, int H,
                 int W, hipStream_t st) {
     switch (C) {
-        case 128: return launch_cl<KS, 2, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 192: return launch_cl<KS, 3, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 256: return launch_cl<KS, 4, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 384: return launch_cl<KS, 6, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
-        case 512: return launch_cl<KS, 8, BF, H2>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 128: return launch_cl<KS, 2, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 192: return launch_cl<KS, 3, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 256: return launch_cl<KS, 4, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 384: return launch_cl<KS, 6, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, st);
+        case 512: return launch_cl<KS, 8, BF, OF>(x, wt, bias, aw, ab, y, B, H, W, st);
     }
     return -22;
 }
@@ -422,15 +457,27 @@ int launch_cl_c(int C, const void* x, const float* wt, const float* bias, const 
 
 // This source is compiled three times (build_native.py): as is (fp32 maps + the entry point), through dwconv_cl_bf16.hip with
 // LVAE_CL_BF16_TU (the bf16-map instances) and through dwconv_cl_h2.hip with LVAE_CL_H2_TU (fp32 maps in, pre-split f16x2 planes out)
-// -- the translation units compile in parallel, the instances take minutes otherwise.
-#if defined(LVAE_CL_H2_TU)
+// and through dwconv_cl_q8.hip with LVAE_CL_Q8_TU (bf16 maps in, MX-fp8 out) -- the translation units compile in parallel, the
+// instances take minutes otherwise.
+#if defined(LVAE_CL_Q8_TU)
+int lvae_dwln_cl_launch_q8(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                           int B, int H, int W, hipStream_t st) {
+    switch (k) {
+        case 1: return launch_cl_c<1, true, 2>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 3: return launch_cl_c<3, true, 2>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 5: return launch_cl_c<5, true, 2>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 7: return launch_cl_c<7, true, 2>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+    }
+    return -22;
+}
+#elif defined(LVAE_CL_H2_TU)
 int lvae_dwln_cl_launch_h2(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
                            int B, int H, int W, hipStream_t st) {
     switch (k) {
-        case 1: return launch_cl_c<1, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
-        case 3: return launch_cl_c<3, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
-        case 5: return launch_cl_c<5, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
-        case 7: return launch_cl_c<7, false, true>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 1: return launch_cl_c<1, false, 1>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 3: return launch_cl_c<3, false, 1>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 5: return launch_cl_c<5, false, 1>(C, x, wt, bias, aw, ab, y, B, H, W, st);
+        case 7: return launch_cl_c<7, false, 1>(C, x, wt, bias, aw, ab, y, B, H, W, st);
     }
     return -22;
 }
@@ -450,13 +497,15 @@ int lvae_dwln_cl_launch_bf16(int C, int k, const void* x, const float* wt, const
                              int B, int H, int W, hipStream_t st);
 int lvae_dwln_cl_launch_h2(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
                            int B, int H, int W, hipStream_t st);
+int lvae_dwln_cl_launch_q8(int C, int k, const void* x, const float* wt, const float* bias, const float* aw, const float* ab, void* y,
+                           int B, int H, int W, hipStream_t st);
 
 // Entry point for pointwise.hip's dispatchers.  Returns 1 when this kernel takes the problem (*rc = launch status), 0 otherwise.
 // Taken for C in {128, 192, 256, 384, 512}, k in {1, 3, 5, 7} and at most ONE per-channel affine after the normalisation -- a rule
 // in (C, k, which pointers are given) only, because this kernel's LayerNorm association differs from the other forms'.
 int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b, const float* shift,
                      const float* scale1p, void* y, int B, int H, int W, int C, int k, int fmt, hipStream_t st, int* rc) {
-    const int bf16 = fmt == 1;                                          // fmt: 0 fp32 maps, 1 bf16 maps, 2 fp32 in / pre-split f16x2 planes out
+    const int bf16 = fmt == 1 || fmt == 3;                              // fmt: 0 fp32 maps, 1 bf16 maps, 2 fp32 in / f16x2 planes out, 3 bf16 in / MX-fp8 out
 #ifdef LVAE_EXPERIMENTAL_BUILD      // tools/build_exp.sh copies only: the kernel family is part of the bitstream contract (its LayerNorm
     static bool env_read = false;   // association differs from the sliding-window kernel's), so the product library has no switch
     if (!env_read) { const char* e = getenv("LVAE_DW_CL"); if (e) g_dw_cl = atoi(e); env_read = true; }
@@ -469,6 +518,7 @@ int lvae_dwln_cl_try(const void* x, const float* wt, const float* bias, const fl
     if ((long)H * W * C * (bf16 ? 2 : 4) > 0x7fffffffL) { *rc = -22; return 1; }
     const float* aw = ln_w ? ln_w : scale1p;
     const float* ab = ln_w ? ln_b : shift;
+    if (fmt == 3) { *rc = lvae_dwln_cl_launch_q8(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
     if (bf16) { *rc = lvae_dwln_cl_launch_bf16(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
     if (fmt == 2) { *rc = lvae_dwln_cl_launch_h2(C, k, x, wt, bias, aw, ab, y, B, H, W, st); return 1; }
     switch (k) {

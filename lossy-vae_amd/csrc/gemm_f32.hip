@@ -682,6 +682,7 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force_tile, i
 int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st);                        // gemm_f32_patch2.hip
 int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st);                         // gemm_f32_conv3.hip
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
+int lvae_gemm_q8_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_q8.hip
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn);
 static int gemm_dispatch(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) { return gemm_dispatch_impl(d, st, x3v2, x3v2_tn); }
 
@@ -698,11 +699,13 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
     if (d->prec < 0 || d->prec > 4) return -22;
     if (d->prec != 3 && (d->a_bf16 || d->out_bf16)) return -22;      // bf16 storage exists in the reduced-precision mode only
-    if (d->prec != 4 && (d->a_h2 || d->out_h2)) return -22;          // pre-split operands belong to the f16x2 arithmetic
+    if (d->prec != 4 && d->prec != 3 && (d->a_h2 || d->out_h2)) return -22;   // pre-converted operands: f16x2 planes (prec 4) / MX-fp8 (prec 3)
     if (d->prec == 3) {
         if ((d->epi == LVAE_EPI_GAMMA_RES || d->epi == LVAE_EPI_RES) && !d->res) return -22;
         if (d->epi == LVAE_EPI_GAMMA_RES && !d->gamma) return -22;
         if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;
+        if (d->a_h2) return lvae_gemm_q8_dispatch(d, (hipStream_t)stream);          // both operands already MX-fp8 in memory
+        if (d->out_h2) return -22;
         return lvae_gemm_lp_dispatch(d, (hipStream_t)stream);
     }
     if (d->prec != 0 && (!d->Wt16 || (d->K & 7) || (d->ldw & 7))) return -22;

@@ -33,6 +33,10 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
                 rc = lvae_dwconv_ln_bf16(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const float*)p[5],
                                          (const float*)p[6], p[7], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], st);
                 break;
+            case LVAE_OP_DWCONV_LN_Q8:
+                rc = lvae_dwconv_ln_q8(p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const float*)p[5],
+                                       (const float*)p[6], p[7], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], st);
+                break;
             case LVAE_OP_STEM_F32:
                 rc = lvae_stem_f32((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (int)i[0], (int)i[1], (int)i[2],
                                    (int)i[3], (float)f[0], (float)f[1], (int*)p[4], st);

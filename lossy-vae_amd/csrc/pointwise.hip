@@ -550,6 +550,14 @@ extern "C" int lvae_dwconv_ln_h2(const float* x, const float* wt, const float* b
     return lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 2, (hipStream_t)stream, &rc) ? rc : -22;
 }
 
+extern "C" int lvae_dwconv_ln_q8(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                                 const float* shift, const float* scale1p, void* y, int B, int H, int W, int C, int k, void* stream) {
+    if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return -22;
+    if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale1p == nullptr)) return -22;
+    int rc = 0;
+    return lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 3, (hipStream_t)stream, &rc) ? rc : -22;
+}
+
 extern "C" int lvae_stem_f32(const float* im, const float* wt, const float* bias, float* out, int B, int H, int W,
                              int Cout, float im_shift, float im_scale, int* range_flag, void* stream) {
     if (!im || !wt || !bias || !out || B <= 0 || (H & 3) || (W & 3) || Cout <= 0 || Cout > 256) return -22;
@@ -763,5 +771,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 15; }
+extern "C" int lvae_abi_version(void) { return 16; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

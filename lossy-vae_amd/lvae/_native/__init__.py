@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 
@@ -37,7 +37,7 @@ class Op(C.Structure):
 
 # lvae_op.kind of every entry point a launch plan may hold (enum LVAE_OP_* of the header, in its order)
 OP_KINDS = {name: k + 1 for k, name in enumerate([
-    'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_stem_f32', 'lvae_stem_bf16',
+    'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_dwconv_ln_q8', 'lvae_stem_f32', 'lvae_stem_bf16',
     'lvae_bias_expand_f32', 'lvae_bias_expand_bf16', 'lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32',
     'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32'])}
 OP_ORDER = len(OP_KINDS) + 1
@@ -62,6 +62,7 @@ SIGNATURES = {
     'lvae_gelu_f32': (_i, [_vp, _vp, _l, _vp]),
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_dwconv_ln_h2': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
+    'lvae_dwconv_ln_q8': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_stem_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'lvae_range_flag_f32': (_i, [_vp, _l, _f, _f, _vp, _vp]),
     'lvae_dwconv_ln_bf16': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),

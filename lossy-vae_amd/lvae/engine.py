@@ -134,6 +134,7 @@ class Plan:
         self.w16 = None        # reduced-precision mode: {fp32 weight address: bf16 copy address} (set by the model's plan)
         self.w16_x3 = None     # f16x2 plans: the bf16x3 map for the GEMMs the f16x2 kernel does not take
         self.w16_k32 = None    # f16x2 plans: weights in the H2K32 plane format for the pre-split-operand GEMMs (csrc/gemm_h2p.hip)
+        self.w16_q8 = None     # fp8 plans: weights in the Q8 format of the pre-quantised-operand GEMMs (csrc/gemm_q8.hip)
         self.graphs = {}       # (lo, hi) -> torch.cuda.CUDAGraph (a hipGraph of that launch range), captured on 2nd use
         self.segments = {}     # (lo, hi, n_ops) -> (lvae_op array, n): the native form of that launch range
         self.seen = set()
@@ -214,6 +215,7 @@ class Plan:
         """Scratch buffers of side-stream ops are separate from the main stream's (they run concurrently)."""
         return name + '_side' if self.on_side else name
 
+    use_q8_pipeline = True             # reduced-precision plans: producer-side quantisation (False: the in-GEMM quantiser everywhere; A/B tool)
     H2P_MIN_ROWS_PER_IMAGE = 1536      # stride-4 / 8 / 16 maps of a 512x768 image; below, the few-tile layers want split-K (gemm_h2.hip)
 
     def mlp_h2p_ok(self, C, hid, k, n_affine=1, rows_per_image=None):
@@ -224,16 +226,24 @@ class Plan:
         return (self.prec == 4 and self.w16_k32 is not None and C in (128, 192, 256, 384, 512) and k in (1, 3, 5, 7) and n_affine <= 1
                 and C % 32 == 0 and hid % 32 == 0 and (rows_per_image is None or rows_per_image >= self.H2P_MIN_ROWS_PER_IMAGE))
 
+    def mlp_q8_ok(self, C, hid, k, n_affine=1):
+        """Reduced-precision plans (prec 3): can the MLP of a ConvNeXt block run with its operands quantised by their PRODUCERS (the
+        depthwise kernel and fc1's epilogue store MX-fp8 + block scales, csrc/gemm_q8.hip streams them by LDS-DMA)?  A rule in the
+        block's shape only: in this mode the two pipelines differ in arithmetic (the producer quantises the fp32 value, the in-GEMM
+        quantiser its bf16 rounding), so encoder and decoder must make the same choice for the same block."""
+        return (self.prec == 3 and self.use_q8_pipeline and self.w16_q8 is not None and C in (128, 192, 256, 384, 512) and k in (1, 3, 5, 7) and n_affine <= 1
+                and C % 64 == 0 and hid % 64 == 0)
+
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
              r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, a_bf16=None, out_bf16=None, a_h2=False,
              out_h2=False, label='gemm'):
         if K is None:
             K = K0 + K1
-        if a_h2:               # both operands pre-split (H2K32 planes): mlp_h2p_ok() said this GEMM qualifies
-            assert self.prec == 4 and Wt16 is None
-            Wt16 = self.w16_k32.get(Wt)
-            assert Wt16, f'{label}: weights do not fit the f16x2 planes'
+        if a_h2:               # both operands pre-converted (f16x2: H2K32 planes; fp8 mode: Q8): mlp_h2p_ok() / mlp_q8_ok() said so
+            assert self.prec in (3, 4) and Wt16 is None
+            Wt16 = (self.w16_k32 if self.prec == 4 else self.w16_q8).get(Wt)
+            assert Wt16, f'{label}: weights do not fit the pre-converted operand format'
         if Wt16 is None and self.w16 is not None:
             Wt16 = self.w16.get(Wt)
         d = GemmDesc()
@@ -252,10 +262,10 @@ class Plan:
         d.prec = (self.prec or 1) if (Wt16 and K % 8 == 0 and not exact) else 0
         d.a_h2, d.out_h2 = int(bool(a_h2)), int(bool(out_h2))
         if a_h2:
-            assert a_mode == _native.A_PLAIN and K1 == 0 and K % 32 == 0 and d.lda0 == K and d.ldw == K, label
+            assert a_mode == _native.A_PLAIN and K1 == 0 and K % (32 if self.prec == 4 else 64) == 0 and d.lda0 == K and d.ldw == K, label
             ksplit = 1
         if out_h2:
-            assert self.prec == 4 and store == _native.ST_ROWMAJOR and N % 32 == 0 and d.ldo == N, label
+            assert self.prec in (3, 4) and store == _native.ST_ROWMAJOR and N % (32 if self.prec == 4 else 64) == 0 and d.ldo == N, label
             ksplit = 1
         if self.prec == 4 and not exact and not a_h2 and not (d.prec == 4 and h2_eligible(d)):
             # f16x2 plans: what csrc/gemm_h2.hip does not take (2x2 patch gathers, K % 32 != 0, a weight beyond fp16's range) runs on
@@ -267,7 +277,7 @@ class Plan:
         if self.prec == 3:
             # reduced-precision plans (BASELINE config 5): bf16 maps in HBM, MX-fp8 operands; weight rows are padded to 64 k
             assert d.prec == 3, f'{label}: no MX-fp8 form of this GEMM (K={K})'
-            d.ldw = (K + 63) // 64 * 64
+            d.ldw = K if a_h2 else (K + 63) // 64 * 64
             d.a_bf16 = 1 if a_bf16 is None else int(a_bf16)
             d.out_bf16 = (0 if store == _native.ST_IMAGE else 1) if out_bf16 is None else int(out_bf16)
             ksplit = 1

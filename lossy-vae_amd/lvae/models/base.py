@@ -91,6 +91,23 @@ def pack_mxfp8(t):
     return torch.cat([q.reshape(-1), eb.to(torch.uint8).reshape(-1)]).contiguous()
 
 
+def pack_mxfp8_q8(t):
+    """An [N][K] fp32 matrix (K % 64 == 0) in the MX-fp8 operand format Q8 of csrc/gemm_q8.hip (include/lvae_hip.h: lvae_gemm_desc.a_h2
+    with prec 3): N*K e4m3 bytes row-major, then the E8M0 block scales as [K/64][N][2].  Same element / scale rule as pack_mxfp8."""
+    n, k = t.shape
+    assert k % 64 == 0
+    buf = pack_mxfp8(t)
+    data, sc = buf[:n * k], buf[n * k:].view(n, k // 64, 2)
+    return torch.cat([data, sc.permute(1, 0, 2).contiguous().reshape(-1)]).contiguous()
+
+
+def unpack_mxfp8_q8(buf, n, k):
+    """Inverse of the Q8 layout (tests): the fp32 values an [n][k] Q8 buffer stands for."""
+    buf = buf.view(torch.uint8).reshape(-1)
+    data, sc = buf[:n * k], buf[n * k:n * k + n * k // 32].view(k // 64, n, 2).permute(1, 0, 2).contiguous().reshape(-1)
+    return unpack_mxfp8(torch.cat([data, sc]), n, k)
+
+
 def unpack_mxfp8(buf, n, k):
     """Inverse of pack_mxfp8 (tests): the fp32 values the MX-fp8 weights stand for, [N][K]."""
     kp = (k + 63) // 64 * 64
@@ -122,6 +139,7 @@ class LazyW16:
             if h is None:
                 c = (pack_bf16x3(t) if self.mode == 'bf16x3' else pack_mxfp8(t) if self.mode == 'mxfp8'
                      else pack_f16x2(t) if self.mode == 'f16x2' else pack_f16x2_k32(t) if self.mode == 'f16x2k32'
+                     else (pack_mxfp8_q8(t) if t.shape[1] % 64 == 0 else None) if self.mode == 'mxfp8q8'
                      else t.to(torch.bfloat16).contiguous())
                 if c is None:                       # f16x2: a weight outside fp16's range
                     self.map[ptr] = 0
@@ -148,6 +166,11 @@ def f16x2_weight_map(tensors):
 
 def f16x2k32_weight_map(tensors):
     m = LazyW16(tensors, 'f16x2k32')
+    return m, m.keep
+
+
+def mxfp8q8_weight_map(tensors):
+    m = LazyW16(tensors, 'mxfp8q8')
     return m, m.keep
 
 

@@ -196,13 +196,14 @@ class _Packed:
     def bf16_map(self, mode):
         """Built once per mode, under a lock: plans are recorded concurrently by the pipeline-group threads, and a second
         builder would free the first one's bf16 copies while its plan still points at them."""
-        from ..base import bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, f16x2k32_weight_map, mxfp8_weight_map, _W16_LOCK
+        from ..base import (bf16_weight_map, bf16x3_weight_map, f16x2_weight_map, f16x2k32_weight_map, mxfp8_weight_map,
+                            mxfp8q8_weight_map, _W16_LOCK)
         with _W16_LOCK:
             if not hasattr(self, '_w16'):
                 self._w16 = {}
             if mode not in self._w16:
                 self._w16[mode] = {'bf16': bf16_weight_map, 'bf16x3': bf16x3_weight_map, 'f16x2': f16x2_weight_map,
-                                   'f16x2k32': f16x2k32_weight_map, 'fp8': mxfp8_weight_map}[mode](self.t)
+                                   'f16x2k32': f16x2k32_weight_map, 'fp8': mxfp8_weight_map, 'mxfp8q8': mxfp8q8_weight_map}[mode](self.t)
         return self._w16[mode][0]
 
 
@@ -216,6 +217,7 @@ class _NetPlan(Plan):
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
         self.w16_k32 = pk.bf16_map('f16x2k32') if self.prec == 4 else None
+        self.w16_q8 = pk.bf16_map('mxfp8q8') if self.prec == 3 else None
         self.lp = self.prec == 3                # reduced precision (BASELINE config 5): feature maps stored as bf16, MX-fp8 GEMMs
         self.adt = torch.bfloat16 if self.lp else torch.float32
         self.dwln = self.lib.lvae_dwconv_ln_bf16 if self.lp else self.lib.lvae_dwconv_ln_f32
@@ -240,8 +242,9 @@ class _NetPlan(Plan):
         off = pk.adaln_off[p]
         # f16x2 plans: y and the hidden map have one consumer each (fc1 / fc2), so their producers store them pre-split (hi / lo' fp16
         # planes, 4 bytes per element like fp32) and the two GEMMs stream both operands by LDS-DMA with no conversion in the main loop
-        h2p = self.mlp_h2p_ok(C, hid, k, rows_per_image=H * W)
-        self.add(lib.lvae_dwconv_ln_h2 if h2p else self.dwln, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
+        # (reduced-precision plans: the same idea with MX-fp8 -- the producers quantise, csrc/gemm_q8.hip streams)
+        h2p = self.mlp_h2p_ok(C, hid, k, rows_per_image=H * W) or self.mlp_q8_ok(C, hid, k)
+        self.add((lib.lvae_dwconv_ln_q8 if self.lp else lib.lvae_dwconv_ln_h2) if h2p else self.dwln, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
                                                                ptr(pk.adaln, off + C), y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
         self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=h.data_ptr(),
                   epi=_native.EPI_BIAS_GELU, a_h2=h2p, out_h2=h2p, label=p + '.fc1')

@@ -286,3 +286,89 @@ def test_config5_mode_noise_per_lambda(typical_model):
         m.set_gemm_precision(base)
     print('config 5 noise floor: ' + '; '.join(f'lambda {l:g}: recon-vs-recon {a:.2f} dB (vs image: {b:.3f} / {c:.3f} dB)' for l, a, b, c in rows))
     assert all(a >= 35.0 for _, a, _, _ in rows), rows
+
+
+# ---------------------------------------------------------------------------------------------- operands quantised by their producers (Q8)
+@pytest.mark.parametrize('tile', [0, 42, 22, 21])
+@pytest.mark.parametrize('M,N,K,epi', [(300, 384, 192, 0), (1000, 192, 384, 2), (129, 64, 512, 3), (520, 448, 256, 2), (4100, 768, 384, 0), (361, 512, 1024, 2)])
+def test_gemm_q8_matches_emulation(L, M, N, K, epi, tile):
+    """csrc/gemm_q8.hip (both operands MX-fp8 in memory, LDS-DMA main loop) against fp64 products of the dequantised operands; bf16 rows
+    out; rows of a smaller call are bit-identical (nothing depends on M), every tile shape gives the same bits."""
+    from lvae.models.base import pack_mxfp8_q8, unpack_mxfp8_q8
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+    A[3, :40] = 0
+    Wt = torch.randn(N, K, generator=g) / K ** 0.5
+    bias, gamma = torch.randn(N, generator=g), torch.rand(N, generator=g)
+    res = _bf(torch.randn(M, N, generator=g))
+    Aq, Wq = pack_mxfp8_q8(A), pack_mxfp8_q8(Wt)
+    Ad, Wd = unpack_mxfp8_q8(Aq, M, K), unpack_mxfp8_q8(Wq, N, K)
+    assert torch.equal(Ad, _mx(A))
+    ref = Ad.double() @ Wd.double().t() + bias.double()
+    ref = {0: ref, 2: res.double() + gamma.double() * ref, 3: res.double() + ref}[epi]
+    out = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    kw = dict(lda0=K, K0=K, Wt16=Wq.cuda(), ldw=K, bias=bias.cuda(), gamma=gamma.cuda(), res=res.cuda(), ldres=N, ldo=N, N=N, K=K, epi=epi,
+              a_h2=1, out_bf16=1, cfg=tile)
+    _gemm(L, A0=Aq.cuda(), out=out, M=M, **kw)
+    err = (out.double().cpu() - ref).abs()
+    scale = (Ad.abs().double() @ Wd.abs().double().t()) + ref.abs() + 1.0
+    assert float((err / scale).max()) <= 2.0 ** -8, float((err / scale).max())
+    if tile == 0:
+        for t2 in (42, 22, 21):
+            o2 = torch.full_like(out, float('nan'))
+            _gemm(L, A0=Aq.cuda(), out=o2, M=M, **{**kw, 'cfg': t2})
+            assert torch.equal(o2, out), t2
+        half = M // 2 | 1                                         # the first rows alone, an ODD number of them (their scales re-laid for that row count)
+        Ah = pack_mxfp8_q8(A[:half])
+        o3 = torch.full((half, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+        _gemm(L, A0=Ah.cuda(), out=o3, M=half, **{**kw, 'res': res[:half].contiguous().cuda()})
+        assert torch.equal(o3, out[:half])
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(1000, 384, 192, 1), (300, 64, 64, 0), (2100, 768, 384, 1)])
+def test_gemm_q8_result_requantised_for_the_next_gemm(L, M, N, K, epi):
+    """out_h2 with prec 3: fc1's GELU output leaves the kernel as MX-fp8 + block scales (Q8).  Against quantising the emulated fp32 result
+    on the host: the same bytes except where the two fp32 values straddle an e4m3 rounding boundary (counted), never further than one
+    e4m3 step of the block's scale."""
+    from lvae.models.base import pack_mxfp8_q8, unpack_mxfp8_q8
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    Wt = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Aq, Wq = pack_mxfp8_q8(A), pack_mxfp8_q8(Wt)
+    ref = unpack_mxfp8_q8(Aq, M, K).double() @ unpack_mxfp8_q8(Wq, N, K).double().t() + bias.double()
+    if epi == 1:
+        ref = F.gelu(ref)
+    out = torch.zeros(M * N + M * N // 32, device='cuda', dtype=torch.uint8)
+    _gemm(L, A0=Aq.cuda(), lda0=K, K0=K, Wt16=Wq.cuda(), ldw=K, bias=bias.cuda(), out=out, ldo=N, M=M, N=N, K=K, epi=epi, a_h2=1, out_h2=1)
+    got = unpack_mxfp8_q8(out.cpu(), M, N)
+    want = unpack_mxfp8_q8(pack_mxfp8_q8(ref.float()), M, N)
+    blockmax = ref.abs().float().view(M, N // 32, 32).amax(2, keepdim=True).expand(M, N // 32, 32).reshape(M, N)
+    diff = (got - want).abs()
+    assert float((diff > 0).float().mean()) <= 5e-3, float((diff > 0).float().mean())
+    assert bool((diff <= blockmax * 2.0 ** -3 + 1e-30).all())
+    assert bool(((got - ref.float()).abs() <= blockmax * 2.0 ** -3 + 1e-30).all())
+
+
+@pytest.mark.parametrize('B,H,W,C,k', [(2, 16, 24, 192, 7), (1, 9, 13, 128, 7), (3, 8, 8, 512, 3), (2, 12, 20, 384, 5), (1, 4, 6, 512, 1)])
+def test_dwconv_ln_q8_quantises_the_fp32_result(L, B, H, W, C, k):
+    """lvae_dwconv_ln_q8 (bf16 map in; depthwise + LayerNorm + AdaLN; MX-fp8 + block scales out) against quantising, on the host, the
+    fp32 result the fp32-map kernel gives for the same (bf16-valued) input."""
+    from lvae.models.base import pack_mxfp8_q8, unpack_mxfp8_q8
+    g = torch.Generator().manual_seed(B + H + W + C + k)
+    xb = _bf(torch.randn(B, H, W, C, generator=g)).cuda()
+    xf = xb.float()
+    wt = (torch.randn(k * k, C, generator=g) / k).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    sh, sc = torch.randn(C, generator=g).cuda(), (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+    y = torch.empty_like(xf)
+    assert L.lvae_dwconv_ln_f32(xf.data_ptr(), wt.data_ptr(), bias.data_ptr(), None, None, sh.data_ptr(), sc.data_ptr(), y.data_ptr(), B, H, W, C, k, _st()) == 0
+    M = B * H * W
+    q = torch.zeros(M * C + M * C // 32, device='cuda', dtype=torch.uint8)
+    assert L.lvae_dwconv_ln_q8(xb.data_ptr(), wt.data_ptr(), bias.data_ptr(), None, None, sh.data_ptr(), sc.data_ptr(), q.data_ptr(), B, H, W, C, k, _st()) == 0
+    torch.cuda.synchronize()
+    got = unpack_mxfp8_q8(q.cpu(), M, C)
+    want = unpack_mxfp8_q8(pack_mxfp8_q8(y.view(M, C).cpu()), M, C)
+    assert float((got != want).float().mean()) <= 1e-3, float((got != want).float().mean())
+    blockmax = y.view(M, C // 32, 32).abs().amax(2, keepdim=True).expand(M, C // 32, 32).reshape(M, C).cpu()
+    assert bool(((got - y.view(M, C).cpu()).abs() <= blockmax * 2.0 ** -3 + 1e-30).all())
