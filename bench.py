@@ -15,6 +15,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                    is copied from the committed rocprofv3 --pmc passes of the same command and labelled so (`traffic_source`);
   roofline_e2e  -- the whole step: algorithmic GEMM FLOPs of one step / ms_per_step against both matrix peaks;
   fp32_mfma_mode_value -- the same workload with the exact fp32 MFMA arithmetic (a few extra steps after the timed region);
+  config5_value -- BASELINE.json configs[4]: the reduced-precision mode (bf16 storage + MX-fp8 MFMA) on 4 x 1216x1216, Mpixels/s
+                   (a few extra steps after the timed region; details in `config5`);
   host_coder    -- rANS encode / decode rate of the native host coder on this step's symbols (Msymbols/s, threads);
   cpu_baseline  -- the CPU oracle (oracle/qarv_oracle.py: the reference's op graph on PyTorch CPU + the plain-C restatement of
                    CompressAI's coder, fed with arrays) on the node's PHYSICAL cores, `cpu_baseline_8core` = the same on 8 threads
@@ -178,6 +180,8 @@ def main():
                          "MX-fp8 MFMA (bf16 / fp8 are not parity paths)")
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the main cpu_baseline row (0 = physical cores)')
     ap.add_argument('--fp32-steps', type=int, default=3, help='extra steps in the exact fp32 MFMA mode (0 = skip)')
+    ap.add_argument('--config5-steps', type=int, default=5,
+                    help='extra steps of BASELINE config 5 (fp8 mode, 4 x 1216x1216) after the timed region -> config5_value (0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -299,6 +303,7 @@ def main():
     e2e_tf = step_gflop / ms_step                          # GFLOP / ms = TFLOP/s
     roofline_e2e = {
         'gemm_gflop_per_step': round(step_gflop, 1), 'ms_per_step': round(ms_step, 3), 'achieved_tflops': round(e2e_tf, 2),
+        'frac_of_f16x2_peak_833.3': round(e2e_tf / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
         'frac_of_bf16x3_peak_416.7': round(e2e_tf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
         'frac_of_fp32_mfma_peak_157.3': round(e2e_tf / PEAK_FP32_MFMA_TFLOPS, 4),
         'note': 'algorithmic 2*M*N*K of EVERY GEMM launch of one step / wall time of the step (host rANS, depthwise and pointwise '
@@ -341,7 +346,8 @@ def main():
                     'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         elif args.precision == 'f16x2':
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0           # fp16 MFMA peak = bf16 MFMA peak; 3 MFMAs per fp32-accurate product step
-            roof = {'bound': 'mfma', 'kernel': 'gemm_h2_kernel<TN, *, 0> (PLAIN GEMM launches; v_mfma_f32_32x32x16_f16 x 3 cross terms)',
+            roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + '
+                                               'gemm_h2_kernel<TN, *, 0> (the other PLAIN GEMM launches); v_mfma_f32_32x32x16_f16 x 3 cross terms',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'peak_note': '2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product step (hi*hi, hi*lo, lo*hi of a 2-term '
                                  f'fp16 split); the same launches against the bf16x3 roof (416.7): {ach / (PEAK_BF16_MFMA_TFLOPS / 6.0):.3f}, '
@@ -355,7 +361,7 @@ def main():
                                  f'peak this launch family runs at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}', **common}
         # HBM bytes per launch of this family: NOT measured in this run (hardware counters cannot be read from inside the process);
         # copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command
-        tfile = {('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r02_pmc_gemm_traffic_fp8_1216.json',
+        tfile = {('f16x2', 8, 512, 768): 'r03_pmc_gemm_traffic.json', ('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r02_pmc_gemm_traffic_fp8_1216.json',
                  ('fp8', 8, 512, 768): 'r02_pmc_gemm_traffic_fp8.json'}.get((args.precision, B, H, W))
         tp = os.path.join(REPO, 'profiles', tfile) if tfile else None
         if tp and not os.path.exists(tp) and args.precision == 'bf16x3':
@@ -380,6 +386,38 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         fp32_mode = round(B * H * W * args.fp32_steps / (time.time() - t1) / 1e6, 3)
+        model.set_gemm_precision(args.precision)
+
+    # BASELINE.json configs[4] beside the headline: the reduced-precision mode (bf16 activation storage + MX-fp8 MFMA GEMMs, operands
+    # quantised by their producers) on 4 x 1216x1216 (1200x1200 padded) -- a few steps after the timed region, product configuration
+    config5 = None
+    if world == 1 and args.config5_steps > 0 and args.precision in ('f16x2', 'bf16x3') and (B, H, W) == (8, 512, 768):
+        try:
+            model.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+            model.set_gemm_precision('fp8')
+            ims5 = synth_batch(4, 1216, 1216, rank).to(dev)
+
+            def step5():
+                s5 = model.compress_batch(ims5)
+                torch.cuda.synchronize(dev)
+                o5 = model.decompress_batch(s5)
+                torch.cuda.synchronize(dev)
+                return s5, o5
+            for _ in range(2):
+                step5()
+            t1 = time.time()
+            for _ in range(args.config5_steps):
+                s5, o5 = step5()
+            dt5 = time.time() - t1
+            config5 = {'value': round(4 * 1216 * 1216 * args.config5_steps / dt5 / 1e6, 3), 'unit': 'Mpixels/s',
+                       'ms_per_step': round(dt5 / args.config5_steps * 1e3, 3), 'steps': args.config5_steps,
+                       'workload': 'qarv_base batch=4 1216x1216 (1200x1200 padded) synthetic, compress_batch+decompress_batch, '
+                                   "set_gemm_precision('fp8'): bf16 activation storage + MX-fp8 (e4m3 + E8M0) MFMA GEMMs; NOT a parity path",
+                       'bpp': round(float(np.mean([len(t) * 8 / (1216 * 1216) for t in s5])), 4),
+                       'psnr_db': round(float(-10 * np.log10(float((o5 - ims5).square().mean()))), 3)}
+            del ims5, o5
+        except Exception as e:                           # never lose the headline line over the side measurement
+            config5 = {'error': repr(e)}
         model.set_gemm_precision(args.precision)
 
     coder = None
@@ -415,7 +453,8 @@ def main():
             'dec_ms_per_step': round((dt - t_enc) / args.steps * 1e3, 3),
             'bpp': round(bpp, 4), 'psnr_db': round(-10 * np.log10(mse), 3),
             'ref_3080ti_mpx_s': 2.47,
-            'roofline': roof, 'roofline_e2e': roofline_e2e, 'fp32_mfma_mode_value': fp32_mode, 'host_coder': coder,
+            'roofline': roof, 'roofline_e2e': roofline_e2e, 'fp32_mfma_mode_value': fp32_mode,
+            'config5_value': None if not config5 else config5.get('value'), 'config5': config5, 'host_coder': coder,
         }
         if world == 1 and not args.no_cpu_baseline:
             phys = args.cpu_threads or physical_cores()

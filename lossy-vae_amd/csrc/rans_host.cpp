@@ -274,7 +274,9 @@ public:
                                                                         // (detached) workers at process exit blocks in pthread_cond_destroy
     void submit(const std::shared_ptr<Job>& j) {
         { std::lock_guard<std::mutex> l(m_); q_.push_back(j); }
-        cv_.notify_all();
+        epoch_.fetch_add(1, std::memory_order_release);           // the spinning workers see this without a futex round trip
+        const int need = j->max_workers < (int)th_.size() ? j->max_workers : (int)th_.size();
+        for (int i = 0; i < need; ++i) cv_.notify_one();          // (notify_all woke all 64 workers for a 4-stream job)
     }
     int size() const { return (int)th_.size(); }
 private:
@@ -282,12 +284,21 @@ private:
         int n = (int)std::thread::hardware_concurrency();
         if (n < 2) n = 2;
         if (n > 64) n = 64;
-        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+        for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i < kSpinners); });
         for (auto& t : th_) t.detach();            // workers live for the process; they only touch heap-owned jobs
     }
-    void loop() {
+    // The decoder calls the pool once per latent block (9 dependent calls per image, 0.1-1 ms of work each, a GPU segment in
+    // between): a worker that goes to sleep on the condition variable after every call costs a futex wake-up (tens of microseconds) on
+    // the critical path of every block.  The first kSpinners workers therefore poll the submit counter for a while (~0.5 ms: longer
+    // than a GPU segment between two blocks) before they block; the others sleep at once.
+    static constexpr int kSpinners = 8;
+    void loop(bool spinner) {
         for (;;) {
             std::shared_ptr<Job> j;
+            if (spinner) {
+                const unsigned seen = epoch_.load(std::memory_order_acquire);
+                for (int it = 0; it < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++it) __builtin_ia32_pause();
+            }
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [this] { return !q_.empty(); });
@@ -307,6 +318,7 @@ public:
 private:
     std::mutex m_;
     std::condition_variable cv_;
+    std::atomic<unsigned> epoch_{0};
     std::deque<std::shared_ptr<Job>> q_;
     std::vector<std::thread> th_;
 };
@@ -324,6 +336,7 @@ void parallel_for(int n, int n_threads, F&& f) {
     j->run = [](void* c, int i) { (*(typename std::remove_reference<F>::type*)c)(i); };
     Pool::get().submit(j);
     Pool::work(*j);
+    for (int it = 0; it < 20000 && j->done.load(std::memory_order_acquire) < n; ++it) __builtin_ia32_pause();   // the stragglers are usually microseconds away
     std::unique_lock<std::mutex> l(j->m);
     j->cv.wait(l, [&] { return j->done.load() >= n; });
 }
