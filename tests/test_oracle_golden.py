@@ -17,7 +17,11 @@ import seeded_init
 from oracle import qarv_oracle
 from oracle import compressai_semantics as cs
 
-FLIP_BUDGET = 2e-3
+# The goldens were generated in the build container (where /root/reference exists) from the imported reference; the oracle issues the same
+# PyTorch CPU ops, so THERE it must reproduce them exactly -- 0 flips, byte-identical containers.  On another host
+# (other CPU, other SIMD width => other summation order) a round() of a value within 1e-6 of .5 may fall the other way: small budget.
+EXACT = os.path.isdir('/root/reference') or os.environ.get('LVAE_ORACLE_EXACT') == '1'
+FLIP_BUDGET = 0.0 if EXACT else 2e-3
 
 
 @pytest.fixture(scope='module')
@@ -105,7 +109,9 @@ def test_full_model(golden_dir, oracle_model, tag, seed):
         if flips == 0 and iflips == 0:
             assert string == g[f'{key}.bitstream'].tobytes()
         xhat = oracle_model.decompress(string)
-        np.testing.assert_allclose(xhat.numpy(), g[f'{key}.xhat'], rtol=0, atol=1e-4 if flips == 0 else 5e-2)
+        if EXACT:
+            assert flips == 0 and iflips == 0 and string == g[f'{key}.bitstream'].tobytes()
+        np.testing.assert_allclose(xhat.numpy(), g[f'{key}.xhat'], rtol=0, atol=2e-6 if EXACT else (1e-4 if flips == 0 else 5e-2))
         assert float(g[f'{key}.xhat_from_z_maxdiff']) == 0.0
         zs = [b['z'] for b in tr['blocks']]
         x2 = oracle_model.decode_from_latents(lmb, zs)

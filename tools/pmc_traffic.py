@@ -47,7 +47,7 @@ def main(fetch_db, write_db, out_json=None):
     for name, n, fm, wm in rows[:40]:
         print(f'{short(name):78s} {n:8d} {fm:16.2f} {2 * fm:10.2f} {wm:16.2f}')
     fam = [r for r in rows if (re.search(r'gemm(_x3|_bf16)?_kernel', r[0]) and r[0].rstrip().endswith(', 0>(lvae_gemm_desc, int, int)'))
-           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, ', r[0])]
+           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<', r[0])]
     n = sum(r[1] for r in fam)
     if n:
         fm = sum(r[1] * r[2] for r in fam) / n
@@ -55,7 +55,7 @@ def main(fetch_db, write_db, out_json=None):
         print(f'# PLAIN GEMM family: {n} launches, fetch {fm:.2f} MB/launch (x2 = {2 * fm:.2f}), write {wm:.2f} MB/launch, '
               f'corrected total {2 * fm + wm:.2f} MB/launch')
         if out_json:
-            json.dump({'family': 'PLAIN GEMM launches (gemm_x3k16/x3w8/x3/lp/gemm kernels, AMODE 0)', 'launches': n,
+            json.dump({'family': 'PLAIN GEMM launches (gemm_h2p/h2/q8/x3k16/x3w8/x3/lp/gemm kernels, AMODE 0)', 'launches': n,
                        'fetch_mb_per_launch_raw': round(fm, 3), 'fetch_mb_per_launch_x2': round(2 * fm, 3),
                        'write_mb_per_launch': round(wm, 3), 'hbm_mb_per_launch_corrected': round(2 * fm + wm, 3),
                        'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE uncalibrated, taken as is'},
