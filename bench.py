@@ -514,7 +514,7 @@ def main():
             # the node's cores as 8-thread oracle processes working on different images at once (a single process scales badly past
             # ~8 threads on these layer sizes: 0.2 Mpixels/s on 128 threads against 0.47 on 8); the single 8-thread figure -- what the
             # reference's README quotes a desktop CPU at -- is kept beside it
-            line['cpu_baseline'] = cpu_baseline(sd, H, W, n_images=4, threads=8, procs=max(1, phys // 8))
+            line['cpu_baseline'] = cpu_baseline(sd, H, W, n_images=3, threads=8, procs=max(1, phys // 8))
             line['cpu_baseline_8core'] = cpu_baseline(sd, H, W, n_images=3, threads=8)
         else:
             line['cpu_baseline'] = None
