@@ -12,7 +12,8 @@
 // in the product build: they compile only together with -DLVAE_EXPERIMENTAL_BUILD, which tools/build_exp.sh passes for its
 // side-by-side copies under _bin/ and lossy-vae_amd/build_native.py never does.
 #if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_NOSPLIT) || defined(LVAE_EXP_NOSTORE) || defined(LVAE_EXP_PRIO) || defined(LVAE_EXP_H2_FULLLINE) || \
-    defined(LVAE_EXP_NO_RES_PREFETCH) || defined(LVAE_EPI_PRIO) || defined(LVAE_GEMM_NOLOAD) || defined(LVAE_GEMM_TRACE) || defined(LVAE_X3V2_TRACE))
+    defined(LVAE_EXP_NO_RES_PREFETCH) || defined(LVAE_EPI_PRIO) || defined(LVAE_GEMM_NOLOAD) || defined(LVAE_GEMM_TRACE) || defined(LVAE_X3V2_TRACE) || \
+    defined(LVAE_EXP_PP_NOWAIT) || defined(LVAE_EXP_PP_NODMA) || defined(LVAE_EXP_PP_NODSR) || defined(LVAE_EXP_PP_NOBAR) || defined(LVAE_EXP_H2PP))
 #error "LVAE_EXP_* / *_TRACE / *_NOLOAD experiment hooks need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh); never in liblvae_hip.so"
 #endif
 

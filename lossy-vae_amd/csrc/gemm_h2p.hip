@@ -197,7 +197,7 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     static int lds_pad = -1;             // experiment knob: extra dynamic LDS (forces one 128-row workgroup per CU)
     if (lds_pad < 0) { const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0; }
-    if (lds_pad > 0) hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
+    if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
     static int stagger = -1;             // experiment knob (default off: measured 0 ... -5 % on the model's shapes)
     if (stagger < 0) { const char* e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0; }
     hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
@@ -208,12 +208,19 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
 
 // Entry point for gemm_f32.hip's dispatcher (prec 4, a_h2 = 1).  force: 0 = choose; 10 * WM + TN = that tile (tuning hook LVAE_H2P_TILE:
 // 42 = 256 x 128, 41 = 256 x 64, 22 = 128 x 128, 21 = 128 x 64).  Every choice gives the same bits.
+#ifdef LVAE_EXP_H2PP
+int lvae_gemm_h2pp_launch(const lvae_gemm_desc* d, hipStream_t st, int tn);        // gemm_h2pp.hip: the persistent-form study (force = 92 / 91)
+#endif
+
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
     if (d->prec != 4 || !d->a_h2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || d->K0 != d->K || (d->K & 31) || d->lda0 != d->K ||
         d->ldw != d->K || d->a_gelu || d->ksplit > 1 || (long)256 * d->K * 4 > 0x7fffffffL)
         return 0;
     const int M = d->M, N = d->N;
     int sel = force;
+#ifdef LVAE_EXP_H2PP
+    if ((sel == 92 || sel == 91) && d->K >= 128 && !(d->K & 63)) { *rc = lvae_gemm_h2pp_launch(d, st, sel - 90); return 1; }
+#endif
     if (sel != 42 && sel != 41 && sel != 22 && sel != 21) {
         // least padded work first (N = 192: three 64-wide tiles, not two 128-wide), then the larger tile if it still fills the chip:
         // 256-row tiles run one workgroup per CU (256 slots), 128-row tiles two (512 slots)
