@@ -108,9 +108,20 @@ def gemmx():
         print(f'M={M:7d} N={N:5d} K={K:5d} epi={epi}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.2f} TF/s')
 
 
+def gemms4():
+    """The stride-4 MLP layers (memory-bound, shallow K): per tile code via LVAE_H2P."""
+    for (M, N, K, epi) in [(196608, 192, 128, 1), (196608, 128, 192, 2), (196608, 384, 192, 1), (196608, 192, 384, 2),
+                           (98304, 192, 128, 1), (98304, 128, 192, 2), (24576, 192, 128, 1), (24576, 128, 192, 2)]:
+        t = bench_gemm(M, N, K, epi)
+        by = 4.0 * M * (K + N) + (4.0 * M * N if epi == 2 else 0)
+        print(f'M={M:7d} N={N:5d} K={K:5d} epi={epi}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.2f} TF/s  {by / t / 1e12:5.2f} TB/s')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gemmx':
         gemmx()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gemms4':
+        gemms4()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemm1':
         M, N, K, epi = [int(v) for v in sys.argv[2:6]]
         t = bench_gemm(M, N, K, epi)
