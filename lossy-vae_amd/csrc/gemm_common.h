@@ -247,6 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
 // Split-K tail: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias) for 16-B chunks of the output.  Shared by the in-kernel
 // reduction (the tile's last-arriving slice workgroup) and by the stand-alone reduce kernel (d.cnt == NULL): same operations in the
 // same order, hence the same bits.
+template <bool H2OUT = false>
 __device__ __forceinline__ void splitk_epilogue_store(const lvae_gemm_desc& d, long m, int c, f32x4 v) {
     if (d.bias) { const f32x4 b = *(const f32x4*)(d.bias + c); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     if (d.epi == LVAE_EPI_BIAS_GELU) {
@@ -259,6 +260,16 @@ __device__ __forceinline__ void splitk_epilogue_store(const lvae_gemm_desc& d, l
     } else if (d.epi == LVAE_EPI_RES) {
         const f32x4 r = *(const f32x4*)(d.res + m * d.ldres + c);
         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    if (H2OUT && d.out_h2) {  // pre-split result (H2K32) for a consumer GEMM with a_h2: serial split-K of gemm_h2p.hip only (ldo == N, N % 32 == 0)
+        unsigned h0, l0, h1, l1;
+        split_pair_h2(v[0], v[1], h0, l0);
+        split_pair_h2(v[2], v[3], h1, l1);
+        const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
+        char* q = (char*)d.out + ((m * d.ldo) << 2) + ((c >> 5) << 7) + ((c & 31) << 1);
+        *(u32x2_t*)q = hi2;
+        *(u32x2_t*)(q + 64) = lo2;
+        return;
     }
     *(f32x4*)(d.out + m * d.ldo + c) = v;
 }

@@ -714,6 +714,12 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
     if (d->store != LVAE_ST_ROWMAJOR && (d->r <= 0 || d->N % (d->r * d->r) || d->H <= 0 || d->W <= 0)) return -22;
     hipStream_t st = (hipStream_t)stream;
     const int S = ksp(d);
+    if (S > 1 && d->prec == 4 && d->a_h2) {
+        // pre-split operands: SERIAL split-K inside gemm_h2p_kernel (one workgroup adds the S slice sums in slice order: the parallel
+        // form's bits without workspace or reduce launch)
+        if (d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S)) return -22;
+        return gemm_dispatch(d, st, x3v2, x3v2_tn);
+    }
     if (S > 1) {
         if (!d->ws || d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S) ||
             (d->prec == 1 && d->K % (64 * S)))
@@ -742,7 +748,7 @@ static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2,
         if (h2p_tile < 0) { const char* e = getenv("LVAE_H2P_TILE"); h2p_tile = e ? atoi(e) : 0; }
         int rc = 0;
         if (d->out_h2 && (d->store != LVAE_ST_ROWMAJOR || (d->epi != LVAE_EPI_BIAS && d->epi != LVAE_EPI_BIAS_GELU) || (d->N & 31) ||
-                          d->ldo != d->N || d->ksplit > 1))
+                          d->ldo != d->N || (d->ksplit > 1 && !d->a_h2)))
             return -22;
         if (d->a_h2) return lvae_gemm_h2p_try(d, st, d->cfg > 0 ? d->cfg : h2p_tile, &rc) ? rc : -22;      // cfg = 10 WM + TN: force a tile
         return lvae_gemm_h2_try(d, st, h2_tn, &rc) ? rc : -22;

@@ -32,7 +32,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define H2P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int WM, int TN, int NBUF>
+// FOLD ("serial split-K", d.ksplit = S > 1 with a_h2): ONE workgroup walks the S contiguous K slices of its tile and adds their partial sums
+// in slice order -- tot = P_0; tot += P_1; ... with P_s = accH_s + accX_s / 2048 -- then applies splitk_epilogue_store: the operations
+// of the parallel form (gemm_h2_kernel with gridDim.y = S + the reduce kernel / last arriver) in the same order, hence the same bits,
+// without workspace traffic or a second launch.  The host takes it when the BATCH gives enough tiles to fill the chip; the slice count
+// itself stays a function of the per-image shape (lvae/engine.py::auto_ksplit), so batched and single-image calls agree bit for bit.
+template <int WM, int TN, int NBUF, bool FOLD = false>
 __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
     using C = Cfg<WM, 2, 2, TN, 1, 32>;
     constexpr int BM = 64 * WM, BN = 64 * TN, ROWS = BM + BN, STAGE = ROWS * 128;
@@ -100,6 +105,28 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accH[a][b][r] = 0.f; accX[a][b][r] = 0.f; }
+    f32x16 tot[FOLD ? 2 : 1][FOLD ? TN : 1];                        // FOLD: running sum of the finished slices
+    const int per = FOLD ? nq / (d.ksplit > 1 ? d.ksplit : 1) : nq;  // stages per K slice
+    int in_slice = 0, slice = 0;
+    auto fold = [&]() __attribute__((always_inline)) {
+        if constexpr (FOLD) {
+            if (++in_slice < per) return;
+            in_slice = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // the slice's partial sum exactly as the parallel form stores it: fma(accX, 2^-11, accH), then the epilogue's
+                        // "+ bias" with no bias (x + 0.0f: turns -0 into +0)
+                        const float pr = __builtin_fmaf(accX[a][b][r], 1.0f / 2048.0f, accH[a][b][r]) + 0.0f;
+                        tot[a][b][r] = slice == 0 ? pr : tot[a][b][r] + pr;
+                        accH[a][b][r] = 0.f; accX[a][b][r] = 0.f;
+                    }
+            ++slice;
+        }
+    };
 
     // prologue: stages 0 .. NBUF-2 in flight (a stage index beyond the last re-reads the last stage into a free buffer: every iteration
     // then issues exactly NI instructions, which keeps the vmcnt arithmetic uniform)
@@ -172,10 +199,29 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
     };
     for (int s = 0; s < nq; s += NBUF) {
         stage_body(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < nq) stage_body(std::integral_constant<int, 1 % NBUF>{}, s + 1);
-        if (NBUF > 2 && s + 2 < nq) stage_body(std::integral_constant<int, 2 % NBUF>{}, s + 2);
+        fold();
+        if (s + 1 < nq) { stage_body(std::integral_constant<int, 1 % NBUF>{}, s + 1); fold(); }
+        if (NBUF > 2 && s + 2 < nq) { stage_body(std::integral_constant<int, 2 % NBUF>{}, s + 2); fold(); }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing (redundant) DMAs have landed before LDS is reused / freed
+    if constexpr (FOLD) {
+        // the reduce kernel's tail on this tile: 4 consecutive columns of one row per lane (quad transpose), then its epilogue function
+        const int lj = li & 3;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = m0 + (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    float v0 = tot[a][b][4 * g + 0], v1 = tot[a][b][4 * g + 1], v2 = tot[a][b][4 * g + 2], v3 = tot[a][b][4 * g + 3];
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    const int c4 = n0 + (wave_n * TN + b) * 32 + (li & ~3);
+                    if (row < d.M && c4 < d.N) splitk_epilogue_store<true>(d, row, c4, (f32x4){v0, v1, v2, v3});
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -185,22 +231,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
     gemm_finish<C>(d, accH, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 }
 
-template <int WM, int TN, int NBUF>
+template <int WM, int TN, int NBUF, bool FOLD = false>
 int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * TN, LDS = NBUF * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     static int lds_pad = -1;             // experiment knob: extra dynamic LDS (forces one 128-row workgroup per CU)
     if (lds_pad < 0) { const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0; }
-    if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
+    if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
     static int stagger = -1;             // experiment knob (default off: measured 0 ... -5 % on the model's shapes)
     if (stagger < 0) { const char* e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
+    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF, FOLD>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
     return (int)hipGetLastError();
 }
 
@@ -214,9 +260,16 @@ int lvae_gemm_h2pp_launch(const lvae_gemm_desc* d, hipStream_t st, int tn);     
 
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
     if (d->prec != 4 || !d->a_h2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || d->K0 != d->K || (d->K & 31) || d->lda0 != d->K ||
-        d->ldw != d->K || d->a_gelu || d->ksplit > 1 || (long)256 * d->K * 4 > 0x7fffffffL)
+        d->ldw != d->K || d->a_gelu || (long)256 * d->K * 4 > 0x7fffffffL)
         return 0;
     const int M = d->M, N = d->N;
+    if (d->ksplit > 1) {
+        // serial split-K (FOLD): S slices of whole 32-deep stages, row-major fp32 / pre-split output with 16-B rows (what the reduce
+        // kernel's epilogue function stores), 128 x 64 tiles (the running sum lives beside two accumulator sets)
+        if ((d->K / 32) % d->ksplit || d->store != LVAE_ST_ROWMAJOR || (N & 3) || (d->ldo & 3) || (d->ldres & 3)) return 0;
+        *rc = launch_h2p<2, 1, 3, true>(d, st);
+        return 1;
+    }
     int sel = force;
 #ifdef LVAE_EXP_H2PP
     if ((sel == 92 || sel == 91) && d->K >= 128 && !(d->K & 63)) { *rc = lvae_gemm_h2pp_launch(d, st, sel - 90); return 1; }

@@ -226,6 +226,36 @@ class Plan:
         return (self.prec == 4 and self.w16_k32 is not None and C in (128, 192, 256, 384, 512) and k in (1, 3, 5, 7) and n_affine <= 1
                 and C % 32 == 0 and hid % 32 == 0 and (rows_per_image is None or rows_per_image >= self.H2P_MIN_ROWS_PER_IMAGE))
 
+    # Serial split-K (gemm_h2p FOLD) against parallel split-K (gemm_h2 + reduce launch) on the few-tile layers: launch-time models fitted
+    # to tools/microbench.py gemmsk on MI355X (profiles/r03_gemm_serial_splitk.txt).  Both forms give the same bits, so -- unlike the slice
+    # count -- this choice may depend on the batch.
+    SERIAL_US_BASE, SERIAL_US_PER_STAGE = 7.0, 0.36            # + per 32-deep stage, times the rounds of 256 tiles of 128 x 64
+    PARALLEL_US_BASE, PARALLEL_US_PER_MELEM = 13.3, 1.83       # + per 1e6 workspace elements (S x M x N, written and re-read)
+
+    def serial_splitk_pays(self, M, N, K, S):
+        tiles = ((M + 127) // 128) * ((N + 63) // 64)
+        serial = self.SERIAL_US_BASE + self.SERIAL_US_PER_STAGE * (K // 32) * max(1.0, tiles / 256.0)
+        parallel = self.PARALLEL_US_BASE + self.PARALLEL_US_PER_MELEM * (S * M * N / 1e6) if S > 1 else serial + 1.0
+        return serial < parallel
+
+    def mlp_pipeline(self, C, hid, k, rows_per_image, n_affine=1):
+        """f16x2 plans: how the MLP of a ConvNeXt block runs.  -> (pre1, pre2, S1, S2): fc1 / fc2 take their A operand pre-split (H2K32
+        planes written by the depthwise kernel / fc1's epilogue) and run as gemm_h2p with S1 / S2 K slices (1 = no split-K; > 1 = the
+        serial form).  Maps of >= 1536 rows per image: always (mlp_h2p_ok).  Smaller maps are the split-K layers: the slice counts are the
+        per-image rule's (auto_ksplit -- the summation order, i.e. the bits), and the pre-split serial form is taken where the BATCH
+        makes it the faster one (serial_splitk_pays); it produces the bits of the parallel form (tests/test_gpu_f16x2.py::
+        test_gemm_h2p_serial_split_k_equals_parallel_split_k), so batched and single-image plans still agree."""
+        if self.mlp_h2p_ok(C, hid, k, n_affine, rows_per_image):
+            return True, True, 1, 1
+        if not self.mlp_h2p_ok(C, hid, k, n_affine, None):
+            return False, False, None, None
+        M = self.B * rows_per_image
+        S1 = auto_ksplit(rows_per_image, hid, C, _native.ST_ROWMAJOR, hid, 0, 4)
+        S2 = auto_ksplit(rows_per_image, C, hid, _native.ST_ROWMAJOR, C, C, 4)
+        pre1 = self.serial_splitk_pays(M, hid, C, S1)
+        pre2 = pre1 and self.serial_splitk_pays(M, C, hid, S2)
+        return pre1, pre2, (S1 if pre1 else None), (S2 if pre2 else None)
+
     def mlp_q8_ok(self, C, hid, k, n_affine=1):
         """Reduced-precision plans (prec 3): can the MLP of a ConvNeXt block run with its operands quantised by their PRODUCERS (the
         depthwise kernel and fc1's epilogue store MX-fp8 + block scales, csrc/gemm_q8.hip streams them by LDS-DMA)?  A rule in the
@@ -263,10 +293,12 @@ class Plan:
         d.a_h2, d.out_h2 = int(bool(a_h2)), int(bool(out_h2))
         if a_h2:
             assert a_mode == _native.A_PLAIN and K1 == 0 and K % (32 if self.prec == 4 else 64) == 0 and d.lda0 == K and d.ldw == K, label
-            ksplit = 1
+            ksplit = (ksplit or 1) if self.prec == 4 else 1        # f16x2: > 1 = serial split-K inside gemm_h2p (mlp_pipeline)
+            assert (K // 32) % ksplit == 0, label
         if out_h2:
             assert self.prec in (3, 4) and store == _native.ST_ROWMAJOR and N % (32 if self.prec == 4 else 64) == 0 and d.ldo == N, label
-            ksplit = 1
+            if not a_h2:
+                ksplit = 1
         if self.prec == 4 and not exact and not a_h2 and not (d.prec == 4 and h2_eligible(d)):
             # f16x2 plans: what csrc/gemm_h2.hip does not take (2x2 patch gathers, K % 32 != 0, a weight beyond fp16's range) runs on
             # the bf16x3 arithmetic -- decided by the GEMM's shape and weights only, so encoder and decoder, batched and single-image
@@ -283,7 +315,9 @@ class Plan:
             ksplit = 1
         if ksplit is None:
             ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
-        if ksplit > 1:
+        if ksplit > 1 and a_h2:
+            d.ksplit = ksplit                                      # serial form: no workspace, no reduce launch
+        elif ksplit > 1:
             d.ksplit, d.ws = ksplit, self.buf(self.sname('splitk_ws'), ksplit * M * N).data_ptr()
             # In-kernel slice reduction (lvae_gemm_desc.cnt: a tile's last-arriving slice workgroup sums the S slabs in place of the
             # second launch) is taken only when the slabs of one tile are small: the last arriver reads S x tile bytes ALONE at the

@@ -243,13 +243,17 @@ class _NetPlan(Plan):
         # f16x2 plans: y and the hidden map have one consumer each (fc1 / fc2), so their producers store them pre-split (hi / lo' fp16
         # planes, 4 bytes per element like fp32) and the two GEMMs stream both operands by LDS-DMA with no conversion in the main loop
         # (reduced-precision plans: the same idea with MX-fp8 -- the producers quantise, csrc/gemm_q8.hip streams)
-        h2p = self.mlp_h2p_ok(C, hid, k, rows_per_image=H * W) or self.mlp_q8_ok(C, hid, k)
-        self.add((lib.lvae_dwconv_ln_q8 if self.lp else lib.lvae_dwconv_ln_h2) if h2p else self.dwln, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
+        # (small maps: the split-K layers -- pre-split + serial split-K where the batch makes that the faster form, same bits: engine.mlp_pipeline)
+        if self.mlp_q8_ok(C, hid, k):
+            pre1, pre2, S1, S2 = True, True, None, None
+        else:
+            pre1, pre2, S1, S2 = self.mlp_pipeline(C, hid, k, H * W)
+        self.add((lib.lvae_dwconv_ln_q8 if self.lp else lib.lvae_dwconv_ln_h2) if pre1 else self.dwln, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off),
                                                                ptr(pk.adaln, off + C), y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
         self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=h.data_ptr(),
-                  epi=_native.EPI_BIAS_GELU, a_h2=h2p, out_h2=h2p, label=p + '.fc1')
+                  epi=_native.EPI_BIAS_GELU, a_h2=pre1, out_h2=pre2, ksplit=S1, label=p + '.fc1')
         self.gemm(A0=h.data_ptr(), K0=hid, M=M, N=C, Wt=pk.p(p + '.fc2_w'), bias=pk.p(p + '.fc2_b'),
-                  gamma=pk.p(p + '.gamma'), res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, a_h2=h2p, label=p + '.fc2')
+                  gamma=pk.p(p + '.gamma'), res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, a_h2=pre2, ksplit=S2, label=p + '.fc2')
 
     def upsample(self, p, m, x, out, H, W):
         pk = self.pk

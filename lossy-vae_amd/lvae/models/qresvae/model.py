@@ -402,14 +402,14 @@ class _QresPlan(Plan):
         C, k, hid = m.dim, m.kernel_size, m.hidden
         M = self.B * H * W
         y, hbuf = self.buf('y', M * C), self.buf('hid', M * hid)
-        h2p = self.mlp_h2p_ok(C, hid, k, rows_per_image=H * W)            # f16x2 plans: pre-split y / hidden map (see the qarv plan's cnx)
-        self.add(lib.lvae_dwconv_ln_h2 if h2p else lib.lvae_dwconv_ln_f32,
+        pre1, pre2, S1, S2 = self.mlp_pipeline(C, hid, k, H * W)        # f16x2 plans: pre-split y / hidden map (see the qarv plan's cnx)
+        self.add(lib.lvae_dwconv_ln_h2 if pre1 else lib.lvae_dwconv_ln_f32,
                  (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), pk.p(p + '.ln_w'), pk.p(p + '.ln_b'), None, None,
                   y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
         self.gemm(A0=y.data_ptr(), K0=C, M=M, N=hid, Wt=pk.p(p + '.fc1_w'), bias=pk.p(p + '.fc1_b'), out=hbuf.data_ptr(),
-                  epi=_native.EPI_BIAS_GELU, a_h2=h2p, out_h2=h2p, label=p + '.fc1')
+                  epi=_native.EPI_BIAS_GELU, a_h2=pre1, out_h2=pre2, ksplit=S1, label=p + '.fc1')
         self.gemm(A0=hbuf.data_ptr(), K0=hid, M=M, N=C, Wt=pk.p(p + '.fc2_w'), bias=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'),
-                  res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, a_h2=h2p, label=p + '.fc2')
+                  res=x, ldres=C, out=out, epi=_native.EPI_GAMMA_RES, a_h2=pre2, ksplit=S2, label=p + '.fc2')
 
     def vdblock(self, p, m, a0, a1, out, H, W):
         """c4(g(c3(g(c2(g(c1(g(x)))))))) with x = a0 or cat[a0, a1] (each of width cin or cin/2)."""

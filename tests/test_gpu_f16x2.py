@@ -262,3 +262,41 @@ def test_gemm_f16x2_patch2_gather(B, Ho, Wo, Cin, Cout):
     one = torch.empty(Ho * Wo, Cout, device='cuda')
     assert _gemm(xn[B - 1].contiguous(), Cin, Cin, Wt, pack_f16x2(Wt), bias, one, Cout, Ho * Wo, a_mode=1, H=Ho, W=Wo, K=K) == 0
     assert torch.equal(one, out[(B - 1) * Ho * Wo:])
+
+
+@pytest.mark.parametrize('M,N,K,S,epi', [(3072, 1024, 512, 4, 1), (3072, 512, 1024, 8, 2), (1536, 1536, 512, 4, 1), (1536, 512, 1536, 6, 2),
+                                         (777, 64, 2048, 16, 0), (2000, 192, 256, 2, 3), (384, 512, 1024, 8, 2), (5000, 96, 128, 2, 1)])
+def test_gemm_h2p_serial_split_k_equals_parallel_split_k(M, N, K, S, epi):
+    """Serial split-K (gemm_h2p FOLD: one workgroup walks the S slices and adds their partial sums in slice order, pre-split operands)
+    against the parallel form on the fp32 operand (gemm_h2_kernel with S slice workgroups per tile + the reduce kernel, and + the
+    in-kernel last arriver): the same operations in the same order => every output bit equal, also with exact zeros and ragged M / N.
+    This is what lets the host pick the form by BATCH size (tiles available) while the slice count stays a per-image rule."""
+    from lvae.models.base import pack_f16x2, pack_f16x2_k32, unpack_f16x2_k32
+    g = torch.Generator().manual_seed(M + N + K + S)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    A[5] = 0.0                                                       # a row of exact zeros (signed-zero handling of the partial sums)
+    A[:, 7] = 0.0
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+    bias[3] = 0.0
+    res = torch.randn(M, N, generator=g).cuda()
+    ws = torch.empty(S * M * N, device='cuda')
+    ref = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, pack_f16x2(Wt), bias, ref, N, M, epi, gamma=gamma, res=res, ksplit=S, ws=ws) == 0
+    cnt = torch.zeros(((M + 63) // 64) * ((N + 31) // 32), dtype=torch.int32, device='cuda')
+    ref2 = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, pack_f16x2(Wt), bias, ref2, N, M, epi, gamma=gamma, res=res, ksplit=S, ws=ws, cnt=cnt) == 0
+    assert not torch.isnan(ref).any() and torch.equal(ref, ref2)
+    Ah, Wh = pack_f16x2_k32(A), pack_f16x2_k32(Wt)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    ws.fill_(float('nan'))                                           # the serial form uses no workspace
+    assert _gemm(Ah, K, K, Wt, Wh, bias, out, N, M, epi, gamma=gamma, res=res, a_h2=1, ksplit=S, ws=ws) == 0
+    assert not torch.isnan(out).any() and torch.equal(out, ref)
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32)) or int((out.view(torch.int32) != ref.view(torch.int32)).sum()) == \
+        int(((out == 0) & (ref == 0) & (out.view(torch.int32) != ref.view(torch.int32))).sum())       # at most signs of exact zeros
+    if N % 32 == 0 and epi in (0, 1):
+        planes = torch.empty(M, N, device='cuda')                    # H2K32 planes: 4 bytes per element
+        assert _gemm(Ah, K, K, Wt, Wh, bias, planes, N, M, epi, a_h2=1, out_h2=1, ksplit=S, ws=ws) == 0
+        got, want = unpack_f16x2_k32(planes, M, N), unpack_f16x2_k32(pack_f16x2_k32(ref), M, N)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+

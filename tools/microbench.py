@@ -108,6 +108,37 @@ def gemmx():
         print(f'M={M:7d} N={N:5d} K={K:5d} epi={epi}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.2f} TF/s')
 
 
+def gemmsk(B=8):
+    """Small-map MLP layers (stride 32 / 64), batch B: parallel split-K on the fp32 operand (gemm_h2 + reduce launch) against the
+    serial form on pre-split operands (gemm_h2p FOLD), slice count from the per-image rule (engine.auto_ksplit)."""
+    from lvae.engine import auto_ksplit
+    from lvae.models.base import pack_f16x2, pack_f16x2_k32
+    for (rows, N, K, epi) in [(384, 1024, 512, 1), (384, 512, 1024, 2), (384, 1536, 512, 1), (384, 512, 1536, 2),
+                              (96, 1024, 512, 1), (96, 512, 1024, 2), (96, 2048, 512, 1), (96, 512, 2048, 2)]:
+        M = B * rows
+        S = auto_ksplit(rows, N, K, 0, N, N, 4)
+        A = torch.randn(M, K, device='cuda')
+        Wt = torch.randn(N, K, device='cuda') / K ** 0.5
+        bias, gamma, res = torch.randn(N, device='cuda'), torch.rand(N, device='cuda'), torch.randn(M, N, device='cuda')
+        out, ws = torch.empty(M, N, device='cuda'), torch.empty(max(1, S) * M * N, device='cuda')
+        keep = []
+
+        def desc(a_h2):
+            d = GemmDesc()
+            w16 = pack_f16x2_k32(Wt) if a_h2 else pack_f16x2(Wt)
+            a = pack_f16x2_k32(A) if a_h2 else A
+            keep.extend([w16, a])
+            d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw, d.bias, d.gamma = a.data_ptr(), K, K, Wt.data_ptr(), w16.data_ptr(), K, bias.data_ptr(), gamma.data_ptr()
+            d.res, d.ldres, d.out, d.ldo, d.M, d.N, d.K, d.epi, d.prec, d.a_h2 = res.data_ptr(), N, out.data_ptr(), N, M, N, K, epi, 4, a_h2
+            if S > 1:
+                d.ksplit, d.ws = S, ws.data_ptr()
+            return d
+        dp, ds = desc(0), desc(1)
+        tp = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(dp), st()))
+        ts = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(ds), st()))
+        print(f'rows/img={rows:4d} B={B} M={M:5d} N={N:5d} K={K:5d} epi={epi} S={S}: parallel {tp * 1e6:7.1f} us   serial {ts * 1e6:7.1f} us')
+
+
 def gemms4():
     """The stride-4 MLP layers (memory-bound, shallow K): per tile code via LVAE_H2P."""
     for (M, N, K, epi) in [(196608, 192, 128, 1), (196608, 128, 192, 2), (196608, 384, 192, 1), (196608, 192, 384, 2),
@@ -122,6 +153,9 @@ if __name__ == '__main__':
         gemmx()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemms4':
         gemms4()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk':
+        for b in (1, 2, 4, 8, 16):
+            gemmsk(b)
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemm1':
         M, N, K, epi = [int(v) for v in sys.argv[2:6]]
         t = bench_gemm(M, N, K, epi)
