@@ -275,11 +275,13 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
     if ((sel == 92 || sel == 91) && d->K >= 128 && !(d->K & 63)) { *rc = lvae_gemm_h2pp_launch(d, st, sel - 90); return 1; }
 #endif
     if (sel != 42 && sel != 41 && sel != 22 && sel != 21) {
-        // least padded work first (N = 192: three 64-wide tiles, not two 128-wide), then the larger tile if it still fills the chip:
-        // 256-row tiles run one workgroup per CU (256 slots), 128-row tiles two (512 slots)
+        // Tile by measurement (profiles/r03_gemm_h2p_tile_sweep.txt: every MLP shape of the model at batch 4 and 8 under each tile):
+        // least padded width first (N = 192: three 64-wide tiles, not two 128-wide); 64-wide: 128 x 64 everywhere; 128-wide: 128 x 64
+        // while 128 x 128 tiles would be fewer than ~4 per CU (the mid-size launches of one pipeline group: more, smaller workgroups
+        // fill the chip and overlap their epilogues), 256 x 128 only for the largest (stride-4, batch 8) launches
         const int tn = (N % 128 == 0 || ((N + 127) / 128) * 128 - N < ((N + 63) / 64) * 64 - N + 1) ? 2 : 1;
-        const long t256 = (long)((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn));
-        sel = (t256 >= 2 * 256 ? 40 : 20) + tn;
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        sel = tn == 1 ? 21 : (t128 < 1024 ? 21 : (t128 >= 4096 ? 42 : 22));
     }
     switch (sel) {
         case 42: *rc = launch_h2p<4, 2, 3>(d, st); break;
