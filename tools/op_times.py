@@ -81,11 +81,16 @@ def main():
         byplan[k[0]] += r[1] / reps
     print(f'total launch time per step (single stream, event-timed): {tot / 1e3:.2f} ms  ' + ', '.join(f'{k}: {v / 1e3:.2f} ms' for k, v in byplan.items()))
     print(f'{"plan":5s} {"op":14s} {"M":>7s} {"N":>5s} {"K":>5s} {"flags":18s} {"calls":>5s} {"us/call":>8s} {"ms/step":>8s} {"pct":>5s} {"TF/s":>6s}')
-    for k, r in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    top = int(os.environ.get('OP_TIMES_TOP', '45'))                # rows printed (the rest is summed in the last line)
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    for k, r in ranked[:top]:
         calls = r[0] // reps
         us = r[1] / r[0]
         tf = r[2] / r[1] / 1e6 if r[2] else 0.0
         print(f'{k[0]:5s} {k[1]:14s} {str(k[2]):>7s} {k[3]:5d} {k[4]:5d} {k[5]:18s} {calls:5d} {us:8.1f} {r[1] / reps / 1e3:8.2f} {100 * r[1] / reps / tot:5.1f} {tf:6.1f}')
+    if len(ranked) > top:
+        rest = ranked[top:]
+        print(f'(+ {len(rest)} more rows: {sum(r[0] for _, r in rest) // reps} calls, {sum(r[1] for _, r in rest) / reps / 1e3:.2f} ms/step)')
 
 
 if __name__ == '__main__':
