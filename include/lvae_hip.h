@@ -177,6 +177,43 @@ enum {
 typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
 int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int* failed_index);
 
+/* One pipeline group's DECODE as a single foreign call (replaces the per-latent-block Python loop around the reference's
+ * `block.decompress` calls, qarv/model.py:531-557; qresvae/model.py:446-454): for every latent block, in order --
+ *   launch its plan segment (up to its prior / index kernel) -> copy its scale indexes to pinned host memory -> wait for the stream ->
+ *   rANS-decode the block's n_images streams (lvae_rans_decode_batch) into pinned host memory -> copy the symbols to the device --
+ * then launch the tail segment (no wait: the caller synchronises).  `strings` / `string_len` are block-major: entry b * n_images + i
+ * is image i's stream of block b.  Index / symbol buffers hold n_images * per_image entries per block, image after image.
+ * Returns 0, a launch error (failed_block = block, failed_op = index in its segment; block n_blocks = the tail), or -74 (EBADMSG) when a
+ * stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional) receive the time spent waiting for the GPU
+ * segments and inside the coder. */
+typedef struct {
+    const lvae_op* ops; int n_ops;
+    const uint8_t* idx_dev; uint8_t* idx_host;        /* n_images * per_image bytes */
+    int32_t* sym_host; int32_t* sym_dev;              /* n_images * per_image int32 */
+    size_t per_image;
+} lvae_dec_block;
+int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings, const size_t* string_len,
+                       const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                       const lvae_op* tail_ops, int n_tail, void* stream, void* side_stream, int n_threads,
+                       int* failed_block, int* failed_op, double* seconds);
+
+/* One pipeline group's ENCODE as a single foreign call (the loop around `block.compress`, qarv/model.py:516-529): launch every block's
+ * segment (through its quantize kernel), each followed by the copies of its symbols / scale indexes to pinned host memory and an event;
+ * then, block by block, wait for its event and rANS-encode its n_images streams (lvae_rans_encode_batch) into out[b * n_images + i]
+ * (capacity out_cap[b * n_images + i]), while the GPU computes the later blocks.  out_len[b * n_images + i] receives the byte count.
+ * `flag_dev` / `flag_host` (optional): the input-range flag of the stem kernel, copied after block 0; a non-zero flag returns -34 (ERANGE)
+ * before anything is coded.  Events are created and destroyed inside the call. */
+typedef struct {
+    const lvae_op* ops; int n_ops;
+    const int32_t* sym_dev; int32_t* sym_host;
+    const uint8_t* idx_dev; uint8_t* idx_host;
+    size_t per_image;
+} lvae_enc_block;
+int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap, long* out_len,
+                       const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                       const int* flag_dev, int* flag_host, void* stream, void* side_stream, int n_threads,
+                       int* failed_block, int* failed_op, double* seconds);
+
 /* Depthwise kxk conv (+bias) -> LayerNorm over C (eps 1e-6, biased variance, no affine) -> AdaLN
  * y*(1+scale)+shift, one pass over an NHWC map (common.py:145-152).  wt is [k*k][C] (tap-major), `ln_w`/`ln_b`
  * (optional, may be NULL) are the LayerNorm affine of qres34m's MyConvNeXtBlock (qresvae/model.py:168-182);

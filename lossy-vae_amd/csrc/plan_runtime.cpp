@@ -8,6 +8,9 @@
 // / wait the fork-join events between the two streams (lvae_stream_order).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <vector>
+
 #include "../../include/lvae_hip.h"
 
 extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int* failed_index) {
@@ -76,5 +79,128 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
             return rc;
         }
     }
+    return 0;
+}
+
+
+namespace {
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+// The decode loop of one pipeline group (lvae/models/*/model.py: decompress_batch) without the interpreter: the chain
+// GPU segment -> indexes to the host -> rANS -> symbols to the device is latency-bound (nine dependent round trips per image), and with
+// two groups decoding from two Python threads every step of it also queued for the interpreter lock.
+extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings,
+                                  const size_t* string_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                  const int32_t* offset, const lvae_op* tail_ops, int n_tail, void* stream, void* side_stream,
+                                  int n_threads, int* failed_block, int* failed_op, double* seconds) {
+    if (!blocks || n_blocks < 0 || n_images <= 0 || !strings || !string_len || !qcdf || !cdf_len || !offset) return -22;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<const uint8_t*> idx_ptr(n_images);
+    std::vector<int32_t*> out_ptr(n_images);
+    std::vector<size_t> cnt(n_images);
+    std::vector<int> status(n_images);
+    double t_gpu = 0.0, t_coder = 0.0;
+    int bad = -1;
+    for (int b = 0; b < n_blocks; ++b) {
+        const lvae_dec_block& k = blocks[b];
+        const double t0 = now_s();
+        int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
+        if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
+        if (rc == 0) rc = (int)hipStreamSynchronize(st);
+        if (rc != 0) {
+            if (failed_block) *failed_block = b;
+            if (failed_op) *failed_op = bad;
+            return rc;
+        }
+        const double t1 = now_s();
+        for (int i = 0; i < n_images; ++i) {
+            idx_ptr[i] = k.idx_host + (size_t)i * k.per_image;
+            out_ptr[i] = k.sym_host + (size_t)i * k.per_image;
+            cnt[i] = k.per_image;
+        }
+        rc = lvae_rans_decode_batch(n_images, strings + (size_t)b * n_images, string_len + (size_t)b * n_images, idx_ptr.data(), cnt.data(),
+                                    qcdf, row_stride, cdf_len, offset, out_ptr.data(), status.data(), n_threads);
+        if (rc != 0) {
+            if (failed_block) *failed_block = b;
+            return -74;
+        }
+        rc = (int)hipMemcpyAsync(k.sym_dev, k.sym_host, k.per_image * n_images * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        if (rc != 0) {
+            if (failed_block) *failed_block = b;
+            return rc;
+        }
+        const double t2 = now_s();
+        t_gpu += t1 - t0; t_coder += t2 - t1;
+    }
+    if (n_tail > 0) {
+        const int rc = lvae_run_ops(tail_ops, n_tail, stream, side_stream, &bad);
+        if (rc != 0) {
+            if (failed_block) *failed_block = n_blocks;
+            if (failed_op) *failed_op = bad;
+            return rc;
+        }
+    }
+    if (seconds) { seconds[0] = t_gpu; seconds[1] = t_coder; }
+    return 0;
+}
+
+extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap,
+                                  long* out_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                  const int* flag_dev, int* flag_host, void* stream, void* side_stream, int n_threads,
+                                  int* failed_block, int* failed_op, double* seconds) {
+    if (!blocks || n_blocks <= 0 || n_images <= 0 || !out || !out_cap || !out_len || !qcdf || !cdf_len || !offset) return -22;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(n_blocks, nullptr);
+    auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    const double t0 = now_s();
+    int bad = -1;
+    for (int b = 0; b < n_blocks; ++b) {
+        const lvae_enc_block& k = blocks[b];
+        int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
+        if (rc == 0) rc = (int)hipMemcpyAsync(k.sym_host, k.sym_dev, k.per_image * n_images * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
+        if (rc == 0 && b == 0 && flag_dev && flag_host) rc = (int)hipMemcpyAsync(flag_host, flag_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (rc == 0) rc = (int)hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+        if (rc == 0) rc = (int)hipEventRecord(ev[b], st);
+        if (rc != 0) {
+            if (failed_block) *failed_block = b;
+            if (failed_op) *failed_op = bad;
+            (void)hipStreamSynchronize(st);
+            cleanup();
+            return rc;
+        }
+    }
+    const double t1 = now_s();
+    std::vector<const int32_t*> sym_ptr(n_images);
+    std::vector<const uint8_t*> idx_ptr(n_images);
+    std::vector<size_t> cnt(n_images);
+    double t_wait = 0.0, t_coder = 0.0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const lvae_enc_block& k = blocks[b];
+        const double tw = now_s();
+        int rc = (int)hipEventSynchronize(ev[b]);
+        const double tc = now_s();
+        t_wait += tc - tw;
+        if (rc == 0 && b == 0 && flag_dev && flag_host && *flag_host != 0) rc = -34;
+        if (rc == 0) {
+            for (int i = 0; i < n_images; ++i) {
+                sym_ptr[i] = k.sym_host + (size_t)i * k.per_image;
+                idx_ptr[i] = k.idx_host + (size_t)i * k.per_image;
+                cnt[i] = k.per_image;
+            }
+            rc = lvae_rans_encode_batch(n_images, sym_ptr.data(), idx_ptr.data(), cnt.data(), qcdf, row_stride, cdf_len, offset,
+                                        out + (size_t)b * n_images, out_cap + (size_t)b * n_images, out_len + (size_t)b * n_images, n_threads);
+        }
+        t_coder += now_s() - tc;
+        if (rc != 0) {
+            if (failed_block) *failed_block = b;
+            (void)hipStreamSynchronize(st);
+            cleanup();
+            return rc;
+        }
+    }
+    cleanup();
+    if (seconds) { seconds[0] = t1 - t0; seconds[1] = t_wait; seconds[2] = t_coder; }
     return 0;
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 
@@ -33,6 +33,18 @@ class GemmDesc(C.Structure):
 class Op(C.Structure):
     """Mirror of `lvae_op` (include/lvae_hip.h): one entry of a native launch-plan segment (lvae_run_ops)."""
     _fields_ = [('kind', C.c_int), ('side', C.c_int), ('p', C.c_void_p * 8), ('i', C.c_long * 6), ('f', C.c_double * 2)]
+
+
+class DecBlock(C.Structure):
+    """Mirror of `lvae_dec_block`: one latent block of a group's decode (lvae_decode_blocks)."""
+    _fields_ = [('ops', C.c_void_p), ('n_ops', C.c_int), ('idx_dev', C.c_void_p), ('idx_host', C.c_void_p), ('sym_host', C.c_void_p),
+                ('sym_dev', C.c_void_p), ('per_image', C.c_size_t)]
+
+
+class EncBlock(C.Structure):
+    """Mirror of `lvae_enc_block`: one latent block of a group's encode (lvae_encode_blocks)."""
+    _fields_ = [('ops', C.c_void_p), ('n_ops', C.c_int), ('sym_dev', C.c_void_p), ('sym_host', C.c_void_p), ('idx_dev', C.c_void_p),
+                ('idx_host', C.c_void_p), ('per_image', C.c_size_t)]
 
 
 # lvae_op.kind of every entry point a launch plan may hold (enum LVAE_OP_* of the header, in its order)
@@ -81,6 +93,8 @@ SIGNATURES = {
     'lvae_event_destroy': (_i, [_vp]),
     'lvae_stream_order': (_i, [_vp, _vp, _vp]),
     'lvae_run_ops': (_i, [_vp, _i, _vp, _vp, _vp]),
+    'lvae_decode_blocks': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'lvae_encode_blocks': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'lvae_sqerr_partials_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
 }

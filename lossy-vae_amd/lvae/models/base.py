@@ -1,9 +1,11 @@
 """Shared host-side machinery of the codecs: batch -> pipeline groups (one HIP stream + one host thread each, so that a
 group's host rANS coding overlaps the other group's GPU work), coder thread budget."""
+import ctypes
 import functools
 import logging
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -230,6 +232,92 @@ class CodecBase(nn.Module):
             self._prec_logged = self._prec
             _log.info('lvae: %s codes with GEMM arithmetic %r%s -- decode with the same mode', type(self).__name__, self._prec,
                       ' (package default)' if self._prec == DEFAULT_PRECISION else ' (set explicitly)')
+
+    # ---- one pipeline group's decode / encode as ONE foreign call (csrc/plan_runtime.cpp: lvae_decode_blocks / lvae_encode_blocks)
+    native_group_loops = os.environ.get('LVAE_PY_GROUP_LOOP') != '1'        # debugging / A-B switch: '1' = the per-block Python loops
+
+    @staticmethod
+    def _group_blocks(pl, kind, cuts, offs, n):
+        """The plan's latent blocks as a native array, cached on the plan: `cuts` = op index after each block's segment, `offs` = its
+        element offset into sym_all / idx_all; per_image from pl.lat_shapes."""
+        from .. import _native
+        key = '_native_blocks_' + kind
+        cached = getattr(pl, key, None)
+        if cached is None:
+            cls = _native.DecBlock if kind == 'dec' else _native.EncBlock
+            arr = (cls * len(cuts))()
+            segs, lo = [], 0
+            for li, cut in enumerate(cuts):
+                seg, n_ops = pl._segment(lo, cut)
+                segs.append(seg)
+                z, hw = pl.lat_shapes[li]
+                o = offs[li]
+                b = arr[li]
+                b.ops, b.n_ops, b.per_image = ctypes.cast(seg, ctypes.c_void_p).value, n_ops, z * hw
+                b.idx_dev, b.idx_host = pl.idx_all.data_ptr() + o, pl.idx_host.data_ptr() + o
+                b.sym_dev, b.sym_host = pl.sym_all.data_ptr() + 4 * o, pl.sym_host.data_ptr() + 4 * o
+                lo = cut
+            tail, n_tail = pl._segment(lo, len(pl.ops)) if kind == 'dec' else (None, 0)
+            cached = (arr, segs, tail, n_tail)
+            setattr(pl, key, cached)
+        return cached
+
+    def _decode_group_native(self, pl, cuts, offs, n, strings, tables, nthreads, stream, T=None):
+        """strings[b][li]: image b's stream of latent block li.  Runs the group's whole decode; the caller copies pl.out afterwards."""
+        from .. import _native
+        arr, _segs, tail, n_tail = self._group_blocks(pl, 'dec', cuts, offs, n)
+        nb = len(cuts)
+        qcdf, cdf_len, offset = tables
+        bufs = [np.frombuffer(strings[b][li], dtype=np.uint8) for li in range(nb) for b in range(n)]      # block-major
+        sp = (ctypes.c_void_p * len(bufs))(*[x.ctypes.data for x in bufs])
+        sl = (ctypes.c_size_t * len(bufs))(*[x.size for x in bufs])
+        fb, fo = ctypes.c_int(-1), ctypes.c_int(-1)
+        secs = (ctypes.c_double * 2)()
+        ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
+        with torch.cuda.device(pl.device):
+            rc = _native.lib().lvae_decode_blocks(arr, nb, n, sp, sl, qcdf.ctypes.data, qcdf.shape[1], cdf_len.ctypes.data, offset.ctypes.data,
+                                                  ctypes.cast(tail, ctypes.c_void_p) if n_tail else None, n_tail, ctypes.c_void_p(stream.cuda_stream),
+                                                  ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
+        if rc == -74:
+            raise ValueError(f'rANS decode failed in latent block {fb.value} (corrupt or truncated bitstream)')
+        if rc != 0:
+            raise RuntimeError(f'native decode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
+        if T is not None:
+            T['dec_gpu_seg'] = T.get('dec_gpu_seg', 0) + secs[0]
+            T['dec_rans'] = T.get('dec_rans', 0) + secs[1]
+
+    def _encode_group_native(self, pl, cuts, offs, n, tables, nthreads, stream, T=None):
+        """Runs the group's whole encode (launches, progressive hand-over, rANS).  -> strings[li][b] (bytes)."""
+        from .. import _native
+        arr, _segs, _tail, _nt = self._group_blocks(pl, 'enc', cuts, offs, n)
+        nb = len(cuts)
+        qcdf, cdf_len, offset = tables
+        caps = [8 * pl.lat_shapes[li][0] * pl.lat_shapes[li][1] + 64 for li in range(nb)]
+        outs = getattr(pl, '_native_enc_out', None)
+        if outs is None:                                   # output buffers live on the plan (one per block and image)
+            outs = pl._native_enc_out = [np.empty(caps[li], dtype=np.uint8) for li in range(nb) for _ in range(n)]
+        op = (ctypes.c_void_p * len(outs))(*[x.ctypes.data for x in outs])
+        oc = (ctypes.c_size_t * len(outs))(*[caps[li] for li in range(nb) for _ in range(n)])
+        out_len = (ctypes.c_long * len(outs))()
+        fb, fo = ctypes.c_int(-1), ctypes.c_int(-1)
+        secs = (ctypes.c_double * 3)()
+        ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
+        flag_dev = pl.range_flag.data_ptr() if getattr(pl, 'range_flag', None) is not None else None
+        flag_host = pl.flag_host.data_ptr() if flag_dev is not None else None
+        with torch.cuda.device(pl.device):
+            rc = _native.lib().lvae_encode_blocks(arr, nb, n, op, oc, out_len, qcdf.ctypes.data, qcdf.shape[1], cdf_len.ctypes.data, offset.ctypes.data,
+                                                  flag_dev, flag_host, ctypes.c_void_p(stream.cuda_stream),
+                                                  ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
+        if rc == -34:
+            pl.raise_if_out_of_range()
+            raise ValueError('input image values must lie in [0, 1]')
+        if rc != 0:
+            raise RuntimeError(f'native encode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
+        if T is not None:
+            T['enc_launch'] = T.get('enc_launch', 0) + secs[0]
+            T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + secs[1]
+            T['enc_rans'] = T.get('enc_rans', 0) + secs[2]
+        return [[outs[li * n + b][:out_len[li * n + b]].tobytes() for b in range(n)] for li in range(nb)]
 
     # ---- test access (not on the hot path)
     @torch.no_grad()

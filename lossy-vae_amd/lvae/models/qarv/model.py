@@ -592,6 +592,17 @@ class VariableRateLossyVAE(CodecBase):
             pl = self._plan('enc', n, H, W, g)
             t0 = time.time()
             pl.im.view(n, 3, H, W).copy_(im[start:start + n])
+            if self.native_group_loops:
+                # the loop below as ONE foreign call (csrc/plan_runtime.cpp::lvae_encode_blocks): no interpreter between the launches,
+                # the event waits and the coder calls, and no interpreter lock shared with the other group's thread
+                per_block = self._encode_group_native(pl, pl.qcuts, pl.sym_off, n, tables, nthreads, stream, T)
+                nl = len(pl.lat_shapes)
+                assert nl == self.num_latents
+                strings = [per_block[li][b] for b in range(n) for li in range(nl)]
+                res = [header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]) for b in range(n)]
+                if T is not None:
+                    T['enc_group_total'] = T.get('enc_group_total', 0) + time.time() - t0
+                return res
             # Progressive hand-over: after each latent block's quantize launch, its symbols / indexes are copied to pinned host
             # memory and an event is recorded; the host then entropy-codes block i while the GPU is still computing blocks > i
             # (only the last block's streams are coded after the GPU has finished).
@@ -628,13 +639,18 @@ class VariableRateLossyVAE(CodecBase):
             stream.synchronize()
             t2 = t1 + t_wait + (time.time() - tw)
             strings = [per_block[li][b] for b in range(n) for li in range(nl)]
+            t_gpu_done = time.time()
+            assert nl == self.num_latents
+            res = [header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]) for b in range(n)]
             if T is not None:
                 t3 = time.time()
                 T['enc_launch'] = T.get('enc_launch', 0) + t1 - t0
                 T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + t2 - t1
                 T['enc_rans'] = T.get('enc_rans', 0) + t3 - t2
-            assert nl == self.num_latents
-            return [header + coding.pack_byte_strings(strings[b * nl:(b + 1) * nl]) for b in range(n)]
+                T['enc_last_wait'] = T.get('enc_last_wait', 0) + t_gpu_done - tw          # final stream.synchronize()
+                T['enc_after_gpu'] = T.get('enc_after_gpu', 0) + t3 - t_gpu_done           # container packing after the GPU is done
+                T['enc_group_total'] = T.get('enc_group_total', 0) + t3 - t0
+            return res
 
         out = []
         for part in self._run_groups(encode_group, groups):
@@ -651,11 +667,13 @@ class VariableRateLossyVAE(CodecBase):
     @on_model_device
     def decompress_batch(self, strings):
         """Decode a list of byte strings that share lambda and latent shape -> (B,3,H,W) tensor in [0,1]."""
+        t_entry = time.time()
         B = len(strings)
         heads = [struct.unpack('f', s[:4]) + struct.unpack('3H', s[4:10]) for s in strings]
         lmb, nB, nH, nW = heads[0]
         assert nB == 1 and all(h == heads[0] for h in heads), 'batch must share lambda and shape'
         lv = [coding.unpack_byte_string(s[10:]) for s in strings]
+        t_a = time.time()
         self._prepare()
         self._set_lmb(lmb)
         tables = self._dg().host_tables()
@@ -663,11 +681,24 @@ class VariableRateLossyVAE(CodecBase):
         nthreads = self._coder_threads_per_group(len(groups))
         T = self.timing
         out = torch.empty(B, 3, nH * self.max_stride, nW * self.max_stride, device=self._dummy.device)
+        t_b = time.time()
+        if T is not None:
+            T['dec_head_parse'] = T.get('dec_head_parse', 0) + t_a - t_entry
+            T['dec_head_setup'] = T.get('dec_head_setup', 0) + t_b - t_a
 
         def decode_group(g, start, n, stream):
+            if T is not None:
+                T['dec_head_thread'] = T.get('dec_head_thread', 0) + time.time() - t_b          # submit -> the group's thread runs
             pl = self._plan('dec', n, nH, nW, g)
             assert all(len(lv[start + b]) == len(pl.cuts) for b in range(n)), f'expected {len(pl.cuts)} strings per image'
             lo = 0
+            if T is not None:
+                T['dec_head'] = T.get('dec_head', 0) + time.time() - t_entry                    # entry -> this group's first launch
+            if self.native_group_loops:
+                # the loop below as ONE foreign call (csrc/plan_runtime.cpp::lvae_decode_blocks)
+                self._decode_group_native(pl, pl.cuts, pl.idx_off, n, [lv[start + b] for b in range(n)], tables, nthreads, stream, T)
+                out[start:start + n].copy_(pl.out, non_blocking=True)
+                return None
             for li, cut in enumerate(pl.cuts):
                 t0 = time.time()
                 pl.run(lo, cut, stream=stream.cuda_stream)
@@ -689,7 +720,12 @@ class VariableRateLossyVAE(CodecBase):
             out[start:start + n].copy_(pl.out, non_blocking=True)
             return None
 
+        if T is not None:
+            t_g = time.time()
         self._run_groups(decode_group, groups)
+        if T is not None:
+            T['dec_groups_total'] = T.get('dec_groups_total', 0) + time.time() - t_g
+            T['dec_calls'] = T.get('dec_calls', 0) + 1
         return out
 
     @torch.no_grad()

@@ -594,6 +594,13 @@ class HierarchicalVAE(CodecBase):
         def decode_group(g, start, n, stream):
             pl = self._plan('dec', n, H, W, g)
             assert all(len(objs[start + b]) - 1 == len(pl.cuts) for b in range(n)), 'wrong number of latent strings'
+            if self.native_group_loops and not pl.lossless:
+                # the loop below as ONE foreign call (csrc/plan_runtime.cpp::lvae_decode_blocks; lossless plans keep the loop: their
+                # last stream uses the output net's tables)
+                self._decode_group_native(pl, pl.cuts, pl.idx_off, n, [[objs[start + b][li][0] for li in range(len(pl.cuts))] for b in range(n)],
+                                          tables, nthreads, stream)
+                out[start:start + n].copy_(pl.out, non_blocking=True)
+                return
             lo = 0
             for li, cut in enumerate(pl.cuts):
                 pl.run(lo, cut, stream=stream.cuda_stream)

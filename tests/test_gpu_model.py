@@ -403,3 +403,35 @@ def test_encode_is_stable_under_stream_concurrency(product_model):
     x = m.decompress_batch(first)
     for _ in range(5):
         assert torch.equal(m.decompress_batch(first), x)
+
+
+def test_native_group_loops_equal_the_python_loops(product_model):
+    """One pipeline group's encode / decode as one foreign call (lvae_encode_blocks / lvae_decode_blocks, csrc/plan_runtime.cpp)
+    against the per-latent-block Python loops they replace: same byte strings, same reconstruction bits, at batch 1 (one group) and
+    batch 5 (two groups of unequal size); an out-of-range input still raises the reference's assertion, a corrupt stream ValueError."""
+    m = product_model
+    ims = torch.cat([_img(128, 192, 40 + i) for i in range(5)], 0).cuda()
+    try:
+        m.native_group_loops = False
+        s_py = m.compress_batch(ims, 300.0)
+        x_py = m.decompress_batch(s_py).clone()
+        s1_py = m.compress(ims[2:3], 300.0)
+        m.native_group_loops = True
+        s_nat = m.compress_batch(ims, 300.0)
+        assert s_nat == s_py
+        assert torch.equal(m.decompress_batch(s_py), x_py)
+        assert m.compress(ims[2:3], 300.0) == s1_py == s_py[2]
+        assert torch.equal(m.decompress(s_py[2])[0], x_py[2])
+        with pytest.raises(AssertionError):
+            m.compress_batch(ims * 1.5, 300.0)                          # values above 1: the stem kernel's range flag
+        assert m.compress_batch(ims, 300.0) == s_py                    # ... and the flag is cleared again
+        bad = bytearray(s_py[0])
+        bad[-30:] = b'\x00' * 30
+        try:
+            out = m.decompress(bytes(bad))
+            assert out.shape == (1, 3, 128, 192)
+        except ValueError:
+            pass
+    finally:
+        m.native_group_loops = True
+
