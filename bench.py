@@ -369,6 +369,9 @@ def main():
         # kernels).  The dominant kernel is therefore timed in `roofline_steps` EXTRA steps of the same workload on a
         # single stream, every such launch bracketed by HIP events on that stream.
         model.pipeline_groups = 1
+        # (the per-launch events need the plans replayed launch by launch from Python: the product path runs a group's whole
+        #  encode / decode as one native call -- lvae_encode_blocks / lvae_decode_blocks -- which has no hook per launch)
+        model.native_group_loops = False
         step()                                           # builds the single-group plans (untimed)
         single = [(k, pl) for k, pl in model._plans.items() if k[1] == B and k[-1] == args.precision]
         for _, pl in single:
@@ -378,6 +381,7 @@ def main():
         torch.cuda.synchronize(dev)
         for _, pl in single:
             del pl.run                                   # back to Plan.run
+        model.native_group_loops = True
         ms, n_launch = timer.summary()
         per_step = sum(2 * d.M * d.N * d.K for d in gemm_descs(single, dominant))
         alg_bytes = sum(alg_bytes_of(d) for d in gemm_descs(single, dominant))
@@ -387,7 +391,7 @@ def main():
         common = {'traffic': None, 'traffic_source': None, 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
                   'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
                   'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
-                  'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region, HIP events around every such launch'}
+                  'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region (plans replayed launch by launch), HIP events around every such launch'}
         if args.precision in ('bf16', 'fp8'):
             kern = {'bf16': 'gemm_bf16_kernel<Cfg<*>, 0> (PLAIN GEMM launches: operands rounded to bf16 on the bf16 MFMA, fp32 maps in HBM)',
                     'fp8': 'gemm_lp_kernel<TN, 0, *, *> (PLAIN GEMM launches of the reduced-precision mode: bf16 maps in HBM, operands '

@@ -262,6 +262,20 @@ def test_config4_eval_sharded_script_and_bench_two_ranks(offline_home, tmp_path)
     assert j['unit'] == 'Mpixels/s' and j['value'] > 0 and abs(j['value'] - 8 * 512 * 768 / (j['ms_per_step'] * 1e3)) < 0.01 * j['value']
 
 
+def test_bench_line_carries_a_measured_roofline(offline_home, tmp_path):
+    """The default single-GPU bench line (short run): the roofline object is MEASURED in that run -- launches > 0, an average launch
+    duration, 0 < frac < 1 -- also now that the product path runs a pipeline group's loop natively (no per-launch hook: the
+    roofline pass replays launch by launch), and value = pixels / time."""
+    out = _run([os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--fp32-steps', '0',
+                '--config5-steps', '0', '--roofline-steps', '1'], offline_home, tmp_path)
+    j = [json.loads(l) for l in out.splitlines() if l.startswith('{')][0]
+    r = j['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['launches'] > 100 and r['avg_launch_us'] > 5
+    assert 0.05 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert abs(j['value'] - 8 * 512 * 768 / (j['ms_per_step'] * 1e3)) < 0.01 * j['value']
+    assert abs(j['ms_per_step'] - j['enc_ms_per_step'] - j['dec_ms_per_step']) < 0.05 * j['ms_per_step']
+
+
 # ------------------------------------------------------------------------------------------------------------------ H2, f2
 def test_speedtest_script(offline_home, tmp_path):
     """scripts/speedtest-lvae.py (reference :13-44,76-88)."""
