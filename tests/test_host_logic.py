@@ -117,6 +117,35 @@ def test_auto_ksplit_is_batch_independent_and_valid():
     assert auto_ksplit(96, 512, 1024, _native.ST_SHUFFLE, 512, 512, 2) == 1
 
 
+def test_mlp_pipeline_keeps_the_slice_count_per_image_and_picks_the_form_by_batch():
+    """engine.Plan.mlp_pipeline: for the split-K layers (maps below 1536 rows per image) the slice counts are auto_ksplit's of the
+    per-image shape at EVERY batch size -- only the form (serial pre-split / parallel) follows the batch; large maps always run
+    pre-split without split-K; fc2 is never pre-split unless fc1 is."""
+    from lvae import _native
+    from lvae.engine import Plan, auto_ksplit
+    RM = _native.ST_ROWMAJOR
+
+    def plan(B):
+        pl = Plan.__new__(Plan)                      # host logic only: no device, no library
+        pl.prec, pl.w16_k32, pl.B = 4, {}, B
+        return pl
+    for rows, C, hid in [(384, 512, 1024), (384, 512, 1536), (96, 512, 1024), (96, 512, 2048)]:
+        s1, s2 = auto_ksplit(rows, hid, C, RM, hid, 0, 4), auto_ksplit(rows, C, hid, RM, C, C, 4)
+        assert s1 > 1 and s2 > 1
+        forms = []
+        for B in (1, 2, 4, 8, 16):
+            pre1, pre2, S1, S2 = plan(B).mlp_pipeline(C, hid, 3, rows)
+            assert (S1 == s1 if pre1 else S1 is None) and (S2 == s2 if pre2 else S2 is None) and (pre1 or not pre2)
+            forms.append((pre1, pre2))
+        assert forms[-1][0]                          # a large batch takes the serial form for fc1
+        assert all(a <= b for a, b in zip(forms, forms[1:]))       # ... monotonically: once serial, serial for larger batches
+    assert plan(1).mlp_pipeline(384, 768, 7, 6144) == (True, True, 1, 1)          # stride-8 map: pre-split, no split-K
+    assert plan(8).mlp_pipeline(384, 768, 7, 6144) == (True, True, 1, 1)
+    assert plan(8).mlp_pipeline(144, 288, 7, 96) == (False, False, None, None)     # a width the pre-split producers do not have
+    pl = plan(8); pl.prec = 2
+    assert pl.mlp_pipeline(512, 1024, 3, 384) == (False, False, None, None)        # other arithmetics: untouched
+
+
 def test_numa_pinning_groups_ranks_by_host(monkeypatch):
     """lvae/utils/numa.pin_ranks_collectively on a faked 2-node x 4-GPU job: ranks are grouped by HOSTNAME (identical cpulists on two
     machines must not be pooled), split their node's cores in global-rank order, and refuse a topology that covers < 90 % of the CPUs."""
