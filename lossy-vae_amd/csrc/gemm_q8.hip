@@ -260,8 +260,11 @@ int lvae_gemm_q8_dispatch(const lvae_gemm_desc* d, hipStream_t st) {
     int sel = d->cfg;
     if (sel != 42 && sel != 22 && sel != 21) {
         const int tn = (N % 128 == 0 || ((N + 127) / 128) * 128 - N < ((N + 63) / 64) * 64 - N + 1) ? 2 : 1;
-        const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128);
-        sel = tn == 1 ? 21 : (t256 >= 2 * 256 ? 42 : 22);          // 64-wide tiles (N = 192: three, none half empty) exist as 128 x 64 only
+        // by measurement (tools/q8_tiles.py, profiles/r03_gemm_q8_tile_sweep.txt): 64-wide tiles (N = 192: three, none half empty) exist as
+        // 128 x 64 only; 128 x 128 is never the fastest; wide-output launches (fc1: N > K, epilogue-heavy) take 256 x 128 only when very
+        // large, deep-K launches (fc2) as soon as there are enough 256-row tiles
+        const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        sel = tn == 1 ? 21 : (N > d->K ? (t128 >= 4096 ? 42 : 21) : (t256 >= 128 ? 42 : 21));
     }
     switch (sel) {
         case 42: return launch_q8<4, 2, 3>(d, st);
