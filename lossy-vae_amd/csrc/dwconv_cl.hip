@@ -39,6 +39,12 @@
 
 #include "../../include/lvae_hip.h"
 
+// Timing studies (WRONG RESULTS by construction; tools/build_exp.sh builds only): LVAE_EXP_DW_NODMA re-reads the tile's first two rows
+// instead of fetching new ones (what is left without the row traffic), LVAE_EXP_DW_NOLN skips the LayerNorm phases and stores.
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_DW_NODMA) || defined(LVAE_EXP_DW_NOLN) || defined(LVAE_EXP_DW_NOREAD))
+#error "LVAE_EXP_DW_* experiment hooks need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh); never in liblvae_hip.so"
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -339,15 +345,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
     static_for<NR>([&](auto t_tag) {                                 // input row y0 - P + t feeds output rows th = t - i, 0 <= i < k
         constexpr int t = decltype(t_tag)::value;
         // row t + 2 -> the buffer row t came from (it is in registers since the end of the previous step)
+#ifndef LVAE_EXP_DW_NODMA
         if constexpr (t + 2 < NR) dma_row(y0 - P + t + 2, t % 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<XW - 1>([&](auto s_tag) {                         // the pixel pair (s, s + 1)
             constexpr int s = decltype(s_tag)::value;
+#ifndef LVAE_EXP_DW_NOLN
             if constexpr (s == LN_AT && t - 1 >= KS - 1) {
                 lds_barrier();
                 ln_finish(y0 + t - 1 - (KS - 1), (t - 1) % 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             const float x0 = xp[s / 2][s % 2], x1 = xp[(s + 1) / 2][(s + 1) % 2];
             f32x2 xv;
             if constexpr (s % 2 == 0) xv = xp[s / 2];
@@ -375,14 +385,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
             // overtake an older load), so they must NOT be added to the allowance: an earlier form that allowed NG + 2 for a row's
             // two stores read half-landed rows under memory load.
             // (Reading the row pixel by pixel behind the taps, each into the register of the pixel that just died, was tried: no gain.)
+#ifdef LVAE_EXP_DW_NODMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(t + 2 < NR ? NG : 0) : "memory");
+#endif
+#ifndef LVAE_EXP_DW_NOREAD
             read_row(std::integral_constant<int, (t + 1) % 2>{});
+#endif
         }
+#ifndef LVAE_EXP_DW_NOLN
         if constexpr (t >= KS - 1) ln_local(acc[t - (KS - 1)], t % 2);
+#else
+        if constexpr (t >= KS - 1) { float sacc = 0.f; for (int q = 0; q < SW / 2; ++q) sacc += acc[t - (KS - 1)][q][0] + acc[t - (KS - 1)][q][1]; if (sacc == 1.2345e30f) ((float*)y)[0] = sacc; }
+#endif
     });
+#ifndef LVAE_EXP_DW_NOLN
     lds_barrier();
     ln_finish(y0 + TH - 1, (NR - 1) % 2);
     lds_barrier();                                     // the statistics buffers are free for the next tile
+#endif
     }
 }
 
