@@ -162,6 +162,19 @@ typedef struct {
                                              loop); out_h2 = 1: the result (EPI_BIAS / EPI_BIAS_GELU, N % 64 == 0, ldo = N) is stored as Q8 */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
+
+/* The MLP of a ConvNeXt block as ONE launch (f16x2 arithmetic, pre-split operands), for the block shape whose weights fit a CU's LDS:
+ * C = 128, hidden = 192 -- the decoder's stride-4 blocks (qarv/zoo.py:86-87; common.py:131-132,154-158):
+ *     out[m][c] = res[m][c] + gamma[c] * ( fc2( gelu_erf( fc1(y)[m] + b1 ) )[c] + b2[c] )
+ * y: H2K32 planes [M][C] (lvae_dwconv_ln_h2); w1: H2K32 [hid][C]; w2: H2K32 [C][hid] (lvae.models.base.pack_f16x2_k32); res / out: fp32
+ * [M][C] (may alias).  Every output bit equals the two lvae_gemm_f32 launches (prec 4, a_h2 / out_h2) it replaces.  -22 for any other
+ * (C, hid). */
+typedef struct {
+    const void* y; const void* w1; const float* b1; const void* w2; const float* b2; const float* gamma;
+    const float* res; float* out;
+    int M, C, hid;
+} lvae_mlp_desc;
+int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
 
 /* Native replay of a recorded launch-plan segment (csrc/plan_runtime.cpp; lvae/engine.py: Plan.run): ONE foreign call instead of one
@@ -172,7 +185,7 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 enum {
     LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_DWCONV_LN_Q8, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
     LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
-    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_ORDER
+    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_ORDER
 };
 typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
 int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int* failed_index);

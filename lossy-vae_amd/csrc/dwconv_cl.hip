@@ -41,7 +41,7 @@
 
 // Timing studies (WRONG RESULTS by construction; tools/build_exp.sh builds only): LVAE_EXP_DW_NODMA re-reads the tile's first two rows
 // instead of fetching new ones (what is left without the row traffic), LVAE_EXP_DW_NOLN skips the LayerNorm phases and stores.
-#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_DW_NODMA) || defined(LVAE_EXP_DW_NOLN) || defined(LVAE_EXP_DW_NOREAD))
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_DW_NODMA) || defined(LVAE_EXP_DW_NOLN) || defined(LVAE_EXP_DW_NOREAD) || defined(LVAE_EXP_DW_LN_AT))
 #error "LVAE_EXP_DW_* experiment hooks need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh); never in liblvae_hip.so"
 #endif
 
@@ -328,7 +328,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oB), ro, (xs * C + chB) * 4, 0, 0);
         }
     };
+#ifdef LVAE_EXP_DW_LN_AT
+    constexpr int LN_AT = LVAE_EXP_DW_LN_AT < XW - 1 ? LVAE_EXP_DW_LN_AT : XW - 2;
+#else
     constexpr int LN_AT = 3;                           // pixel step of the next row at which the previous row's LayerNorm is finished
+#endif
 
     // The k x k weights (49 dword loads per lane, as many vector-memory instructions as 12 rows of DMA) are loaded once per workgroup and
     // serve tpw tiles; the launcher picks tpw so that the workgroups still fill the chip in whole rounds.

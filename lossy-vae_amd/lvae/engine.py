@@ -339,6 +339,25 @@ class Plan:
         self.flops += 2 * M * N * K
         self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)
 
+    FUSED_MLP_SHAPE = (128, 192)       # (C, hidden) of csrc/mlp_h2f.hip: the decoder's stride-4 blocks
+
+    def mlp_fused_ok(self, C, hid, k, n_affine=1):
+        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2f.hip)?  A rule in the block's shape only; its bits are the
+        two-launch path's (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms)."""
+        return (C, hid) == self.FUSED_MLP_SHAPE and self.mlp_h2p_ok(C, hid, k, n_affine, None)
+
+    def mlp_fused(self, *, y, M, C, hid, w1, b1, w2, b2, gamma, res, out, label='mlp'):
+        """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2): lvae_mlp_h2f."""
+        assert self.prec == 4 and (C, hid) == self.FUSED_MLP_SHAPE
+        w1h, w2h = self.w16_k32.get(w1), self.w16_k32.get(w2)
+        assert w1h and w2h, f'{label}: weights do not fit the pre-split operand format'
+        d = _native.MlpDesc()
+        d.y, d.w1, d.b1, d.w2, d.b2, d.gamma, d.res, d.out = y, w1h, b1, w2h, b2, gamma, res, out
+        d.M, d.C, d.hid = M, C, hid
+        self.keep.append(d)
+        self.flops += 4 * M * C * hid
+        self.add(self.lib.lvae_mlp_h2f, (ctypes.byref(d),), label)
+
     # ---- execution
     # opt-in: measured +-0.5% at B=1 (the path is GPU-latency-bound, not launch-bound) and HIP's global capture mode
     # conflicts with the two pipeline-group threads launching concurrently (hipErrorStreamCaptureInvalidated).

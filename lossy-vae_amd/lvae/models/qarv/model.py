@@ -244,6 +244,13 @@ class _NetPlan(Plan):
         # planes, 4 bytes per element like fp32) and the two GEMMs stream both operands by LDS-DMA with no conversion in the main loop
         # (reduced-precision plans: the same idea with MX-fp8 -- the producers quantise, csrc/gemm_q8.hip streams)
         # (small maps: the split-K layers -- pre-split + serial split-K where the batch makes that the faster form, same bits: engine.mlp_pipeline)
+        if self.mlp_fused_ok(C, hid, k):
+            # C = 128 / hidden = 192 (the decoder's stride-4 blocks): fc1 -> GELU -> fc2 as one launch, the hidden tile never leaves the CU
+            self.add(lib.lvae_dwconv_ln_h2, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off), ptr(pk.adaln, off + C),
+                                             y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
+            self.mlp_fused(y=y.data_ptr(), M=M, C=C, hid=hid, w1=pk.p(p + '.fc1_w'), b1=pk.p(p + '.fc1_b'), w2=pk.p(p + '.fc2_w'),
+                           b2=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'), res=x, out=out, label=p + '.mlp')
+            return
         if self.mlp_q8_ok(C, hid, k):
             pre1, pre2, S1, S2 = True, True, None, None
         else:

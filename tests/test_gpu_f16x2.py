@@ -300,3 +300,36 @@ def test_gemm_h2p_serial_split_k_equals_parallel_split_k(M, N, K, S, epi):
         got, want = unpack_f16x2_k32(planes, M, N), unpack_f16x2_k32(pack_f16x2_k32(ref), M, N)
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
+
+@pytest.mark.parametrize('M', [128, 1000, 24576 + 77, 98304])
+def test_mlp_h2f_equals_two_gemms(M):
+    """The fused MLP of the C = 128 / hidden = 192 blocks (csrc/mlp_h2f.hip: fc1 -> GELU -> fc2 in one launch, the hidden tile in LDS)
+    against the two pre-split GEMM launches it replaces (fc1 with the pre-split GELU epilogue, fc2 with gamma + residual): every
+    output bit equal -- ragged M, wide-range rows, zero rows -- and in place (out aliasing the residual) like the plans use it."""
+    from lvae import _native
+    from lvae.models.base import pack_f16x2_k32
+    C, HID = 128, 192
+    g = torch.Generator().manual_seed(M)
+    yf = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    yf[3] = 0.0
+    W1 = (torch.randn(HID, C, generator=g) / C ** 0.5).cuda()
+    W2 = (torch.randn(C, HID, generator=g) / HID ** 0.5).cuda()
+    b1, b2, gamma = torch.randn(HID, generator=g).cuda(), torch.randn(C, generator=g).cuda(), torch.rand(C, generator=g).cuda()
+    res = torch.randn(M, C, generator=g).cuda()
+    y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+    hid = torch.empty(M, HID, device='cuda')                           # H2K32 planes, 4 bytes per element
+    ref = torch.full((M, C), float('nan'), device='cuda')
+    assert _gemm(y, C, C, W1, w1h, b1, hid, HID, M, 1, a_h2=1, out_h2=1) == 0
+    assert _gemm(hid, HID, HID, W2, w2h, b2, ref, C, M, 2, gamma=gamma, res=res, a_h2=1) == 0
+    d = _native.MlpDesc()
+    out = res.clone()                                                # in place: out aliases the residual
+    d.y, d.w1, d.b1, d.w2, d.b2, d.gamma = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr()
+    d.res, d.out, d.M, d.C, d.hid = out.data_ptr(), out.data_ptr(), M, C, HID
+    assert _native.lib().lvae_mlp_h2f(ctypes.byref(d), _st()) == 0
+    torch.cuda.synchronize()
+    assert not torch.isnan(ref).any() and torch.equal(out, ref)
+    ref64 = res.double() + gamma.double() * (F.gelu(yf.double() @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double())
+    assert float((out.double() - ref64).abs().max()) < 1e-4 * float(ref64.abs().max())
+    d.hid = 256
+    assert _native.lib().lvae_mlp_h2f(ctypes.byref(d), _st()) == -22
+

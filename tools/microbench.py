@@ -139,6 +139,30 @@ def gemmsk(B=8):
         print(f'rows/img={rows:4d} B={B} M={M:5d} N={N:5d} K={K:5d} epi={epi} S={S}: parallel {tp * 1e6:7.1f} us   serial {ts * 1e6:7.1f} us')
 
 
+def mlpf():
+    """C = 128 / hidden = 192 MLP (decoder stride-4 blocks): two pre-split GEMM launches against the fused kernel (csrc/mlp_h2f.hip)."""
+    from lvae._native import MlpDesc
+    from lvae.models.base import pack_f16x2_k32
+    C, HID = 128, 192
+    for M in (196608, 98304, 49152, 24576):
+        yf = torch.randn(M, C, device='cuda')
+        W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
+        b1, b2, gamma = torch.randn(HID, device='cuda'), torch.randn(C, device='cuda'), torch.rand(C, device='cuda')
+        res, out, hid = torch.randn(M, C, device='cuda'), torch.empty(M, C, device='cuda'), torch.empty(M, HID, device='cuda')
+        y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+        d1, d2 = GemmDesc(), GemmDesc()
+        d1.A0, d1.lda0, d1.K0, d1.Wt, d1.Wt16, d1.ldw, d1.bias, d1.out, d1.ldo = y.data_ptr(), C, C, W1.data_ptr(), w1h.data_ptr(), C, b1.data_ptr(), hid.data_ptr(), HID
+        d1.M, d1.N, d1.K, d1.epi, d1.prec, d1.a_h2, d1.out_h2 = M, HID, C, 1, 4, 1, 1
+        d2.A0, d2.lda0, d2.K0, d2.Wt, d2.Wt16, d2.ldw, d2.bias, d2.gamma = hid.data_ptr(), HID, HID, W2.data_ptr(), w2h.data_ptr(), HID, b2.data_ptr(), gamma.data_ptr()
+        d2.res, d2.ldres, d2.out, d2.ldo, d2.M, d2.N, d2.K, d2.epi, d2.prec, d2.a_h2 = res.data_ptr(), C, out.data_ptr(), C, M, C, HID, 2, 4, 1
+        m = MlpDesc()
+        m.y, m.w1, m.b1, m.w2, m.b2, m.gamma, m.res, m.out = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr(), res.data_ptr(), out.data_ptr()
+        m.M, m.C, m.hid = M, C, HID
+        t2 = timeit(lambda: (L.lvae_gemm_f32(ctypes.byref(d1), st()), L.lvae_gemm_f32(ctypes.byref(d2), st())))
+        t1 = timeit(lambda: L.lvae_mlp_h2f(ctypes.byref(m), st()))
+        print(f'M={M:7d}: fc1 + fc2 launches {t2 * 1e6:7.1f} us   fused {t1 * 1e6:7.1f} us   ({4.0 * M * C * HID / t1 / 1e12:6.1f} TF/s, {12.0 * M * C / t1 / 1e12:5.2f} TB/s of y + res + out)')
+
+
 def gemms4():
     """The stride-4 MLP layers (memory-bound, shallow K): per tile code via LVAE_H2P."""
     for (M, N, K, epi) in [(196608, 192, 128, 1), (196608, 128, 192, 2), (196608, 384, 192, 1), (196608, 192, 384, 2),
@@ -153,6 +177,8 @@ if __name__ == '__main__':
         gemmx()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemms4':
         gemms4()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mlpf':
+        mlpf()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk':
         for b in (1, 2, 4, 8, 16):
             gemmsk(b)
