@@ -352,6 +352,12 @@ def main():
     # whole-step algorithmic GEMM FLOPs (every GEMM launch of the encode + decode plans of the timed configuration)
     timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
     step_gflop = sum(2.0 * d.M * d.N * d.K for d in gemm_descs(timed_plans, any_gemm)) / 1e9
+    from lvae._native import MlpDesc                        # + the fused fc1 -> GELU -> fc2 launches (csrc/mlp_h2f.hip): two GEMMs each
+    for _, pl in timed_plans:
+        for fn, a, label, _side in pl.ops:
+            if fn is _nat.lib().lvae_mlp_h2f:
+                m = ctypes.cast(a[0], ctypes.POINTER(MlpDesc)).contents
+                step_gflop += 4.0 * m.M * m.C * m.hid / 1e9
     ms_step = dt / args.steps * 1e3
     e2e_tf = step_gflop / ms_step                          # GFLOP / ms = TFLOP/s
     roofline_e2e = {
@@ -359,8 +365,8 @@ def main():
         'frac_of_f16x2_peak_833.3': round(e2e_tf / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
         'frac_of_bf16x3_peak_416.7': round(e2e_tf / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
         'frac_of_fp32_mfma_peak_157.3': round(e2e_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-        'note': 'algorithmic 2*M*N*K of EVERY GEMM launch of one step / wall time of the step (host rANS, depthwise and pointwise '
-                'kernels included in the time, not in the FLOPs)'}
+        'note': 'algorithmic 2*M*N*K of EVERY GEMM launch of one step (the fused MLP launches counted as their two GEMMs) / wall time of the '
+                'step (host rANS, depthwise and pointwise kernels included in the time, not in the FLOPs)'}
 
     roof = None
     if not args.no_kernel_timing:
