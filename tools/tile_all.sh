@@ -1,8 +1,8 @@
 #!/bin/bash
-# every MLP shape of the model at batch $1 (default 4) under each gemm_h2p tile: which tile wins where
+# every MLP shape of the model at batch $1 (default 4) under each gemm_h2p tile ($TILES, default "21 22 41 42"): which tile wins where
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r3
 B=${1:-4}
-for t in 21 22 41 42; do echo "== tile $t"; LVAE_PREC=4 LVAE_H2P=$t LVAE_OUT_H2=1 timeout 300 python tools/microbench.py gemm $B 2>&1 | grep -v amdgpu | grep -v "^s32\|^s64\|total\|---"; done > gpurun_out/r3/tile_all_b$B.txt 2>&1
+for t in ${TILES:-21 22 41 42}; do echo "== tile $t"; LVAE_PREC=4 LVAE_H2P=$t LVAE_OUT_H2=1 timeout 300 python tools/microbench.py gemm $B 2>&1 | grep -v amdgpu | grep -v "^s32\|^s64\|total\|---"; done > gpurun_out/r3/tile_all_b$B.txt 2>&1
 python - <<PY
 import re,collections
 rows=collections.OrderedDict(); t=None
