@@ -82,10 +82,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
     const unsigned w1_row = lds0 + F_A_BYTES + (96 * wn + li) * 128;
     const unsigned w2_row = lds0 + F_HID_BYTES + (64 * wn + li) * 128;
 
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    LVAE_FENCE();
-
-    // ---- phase 1: P[32 x 96] = y W1^T over K = 128
+    // ---- phase 1: P[32 x 96] = y W1^T over K = 128; stage q is computed as soon as it has landed (five DMA instructions per wave and
+    // stage, issued in stage order: "at most 5 (3 - q) outstanding" = my part of stage q is in LDS; the barrier makes it everyone's)
     f32x16 pH[3], pX[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b)
@@ -93,6 +91,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
         for (int r = 0; r < 16; ++r) { pH[b][r] = 0.f; pX[b][r] = 0.f; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (q == 0) asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory");
+        else if (q == 1) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+        else if (q == 2) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        LVAE_FENCE();
         f16x8 af[2][2], wf[2][3][2];                                  // [t][plane], [t][b][plane]
         const unsigned aq = a_row + q * (F_BM * 128), wq = w1_row + q * F_W1_STAGE;     // (the 16-bit offset field cannot hold these)
 #pragma unroll
