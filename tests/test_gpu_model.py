@@ -151,6 +151,32 @@ def test_batch_equals_single(product_model):
         assert torch.equal(xb[i:i + 1], m.decompress(single[i]))
 
 
+def test_batch_of_8_equals_singles_across_split_k_forms(product_model):
+    """8 x 512x768: stride-32 MLPs (fc2, K = 1024) of the two 4-image pipeline groups take the SERIAL split-K form where the single-image
+    calls take the parallel one (engine.Plan.mlp_pipeline picks the form by batch, the slice count per image) -- strings and
+    reconstructions must still be identical, image by image; the same through one 8-image group."""
+    m = product_model
+    from lvae.engine import Plan
+    pl1, pl4 = Plan.__new__(Plan), Plan.__new__(Plan)
+    pl1.prec = pl4.prec = 4
+    pl1.w16_k32 = pl4.w16_k32 = {}
+    pl1.B, pl4.B = 1, 4
+    assert pl1.mlp_pipeline(512, 1024, 3, 384) != pl4.mlp_pipeline(512, 1024, 3, 384)    # the two forms really differ at this size
+    ims = torch.cat([_img(512, 768, 60 + i) for i in range(8)], 0).cuda()
+    batch = m.compress_batch(ims, 700.0)
+    single = [m.compress(ims[i:i + 1], 700.0) for i in range(8)]
+    assert batch == single
+    xb = m.decompress_batch(batch)
+    for i in (0, 3, 7):
+        assert torch.equal(xb[i:i + 1], m.decompress(single[i]))
+    groups = m.pipeline_groups
+    try:
+        m.pipeline_groups = 1
+        assert m.compress_batch(ims, 700.0) == batch and torch.equal(m.decompress_batch(batch), xb)
+    finally:
+        m.pipeline_groups = groups
+
+
 def test_decode_is_deterministic_and_noise_image(product_model):
     m = product_model
     im = _img(64, 128, 3, kind='noise').cuda()
