@@ -395,7 +395,14 @@ class CodecBase(nn.Module):
             with torch.cuda.stream(st):
                 return fn(g, groups[g][0], groups[g][1], st)
         futs = [self._pool.submit(work, g) for g in range(len(groups))]
-        res = [f.result() for f in futs]
+        res, err = [], None
+        for f in futs:                                    # every group finishes before an error is raised: the plans and streams
+            try:                                          # of a failed call must be idle when the caller tries again
+                res.append(f.result())
+            except BaseException as e:                    # noqa: BLE001
+                err = err or e
+        if err is not None:
+            raise err
         cur = torch.cuda.current_stream(dev)
         for g in range(len(groups)):                      # caller's stream sees the groups' results
             cur.wait_stream(self._streams[g])
