@@ -78,6 +78,13 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
     unsigned po[4];                                                   // [2p + t]
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) po[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xr) << 4);
+    // the hidden tile uses the piece permutation rot3((row >> 1) & 7) instead of (row >> 1) & 7: any bijection keeps the fragment reads
+    // conflict-free, and this one also separates rows m and m + 2 in epilogue 1's ds_write_b64 pattern (4 rows x 4 column groups per
+    // 16 lanes), which the plain form maps to the same banks (two-way conflicts on 31 % of the kernel's LDS cycles: r03_pmc_mlp_h2f.txt)
+    const int xh = ((xr << 1) & 7) | (xr >> 2);
+    unsigned ph[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) ph[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xh) << 4);
     const unsigned a_row = lds0 + (32 * wm + li) * 128;               // A / hidden rows of this wave
     const unsigned w1_row = lds0 + F_A_BYTES + (96 * wn + li) * 128;
     const unsigned w2_row = lds0 + F_HID_BYTES + (64 * wn + li) * 128;
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
                 split_pair_h2(v0, v1, h0, l0);
                 split_pair_h2(v2, v3, h1, l1);
                 const int m = 32 * wm + 4 * lh + 8 * g + lj;          // row (inside the tile) this lane now holds
-                const int x = (m >> 1) & 7;
+                const int k = (m >> 1) & 7, x = ((k << 1) & 7) | (k >> 2);
                 const unsigned base = lds0 + cs * (F_BM * 128) + m * 128 + ((cc & 7) << 1);
                 const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
                 asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 0) ^ x) << 4)), "v"(hi2) : "memory");
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
         const unsigned aq = a_row + q * (F_BM * 128), wq = w2_row + (q & 3) * F_W2_STAGE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            H2F_DSR(af[t][0], aq + po[0 + t], 0);
-            H2F_DSR(af[t][1], aq + po[2 + t], 0);
+            H2F_DSR(af[t][0], aq + ph[0 + t], 0);
+            H2F_DSR(af[t][1], aq + ph[2 + t], 0);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 H2F_DSR(wf[t][b][0], wq + po[0 + t], b * 4096);
