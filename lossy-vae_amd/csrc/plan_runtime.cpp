@@ -108,7 +108,13 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
         const double t0 = now_s();
         int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
         if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
-        if (rc == 0) rc = (int)hipStreamSynchronize(st);
+        if (rc == 0) {
+            // the segment is ~0.3 ms of GPU work and the coder is waiting for it: poll the stream for a bounded while (the wake-up of a
+            // blocking wait is on the chain nine times per image: -0.05 ... 0.08 ms per decode, same-box), then block
+            hipError_t q = hipErrorNotReady;
+            for (int it = 0; it < 400000 && (q = hipStreamQuery(st)) == hipErrorNotReady; ++it) {}
+            rc = q == hipErrorNotReady ? (int)hipStreamSynchronize(st) : (int)q;
+        }
         if (rc != 0) {
             if (failed_block) *failed_block = b;
             if (failed_op) *failed_op = bad;
