@@ -76,6 +76,25 @@ int lvae_rans_decode_batch(int n_streams, const uint8_t* const* in, const size_t
                            const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
                            int32_t* const* sym_out, int* status, int n_threads);
 
+/* ------------------------------------------------------------------------------------------------ status word
+ * One device int per launch plan, zeroed by the caller, OR-ed into by the kernels that are handed its address, copied to the host at
+ * synchronisation points the codec already has (lvae_encode_blocks / lvae_decode_blocks do it per latent block).
+ *   RANGE            an input pixel outside [0, 1] or NaN -- the reference's `assert 0 <= im.min() <= im.max() <= 1`
+ *                    (qarv/model.py:219-220, qresvae/model.py:492), raised by the stem / range kernels;
+ *   NONFINITE_PRIOR  a prior parameter (mean or log-scale, qarv/model.py:51-53) is NaN / inf        (lvae_prior_index_f32,
+ *                    lvae_lossless_params_f32);
+ *   NONFINITE_LATENT a posterior mean / quantised latent is NaN / inf or does not fit an int32      (lvae_quantize_f32);
+ *   NONFINITE_IMAGE  a reconstruction value is NaN / inf before the final clamp                     (ST_IMAGE store, lvae_lossless_output_f32).
+ * Why: the reference computes its 1x1 convs / MLPs in fp32 (common.py:154, qarv/model.py:36-39) and cannot overflow at 65504; the default
+ * arithmetic here (prec 4, "f16x2") splits every operand into fp16 terms, so an activation >= 65520 becomes inf in its hi term.  An
+ * inf / NaN never turns back into a finite value on the way (MFMA sums, GELU, residual adds, LayerNorm all propagate it), and every
+ * tensor of the codec ends in one of the three sinks above -- the encoder's features in a posterior mean, the top-down state in the next
+ * prior or in the image -- so checking the sinks catches every overflow before a byte string or an image is returned.  The Python host
+ * raises lvae.NonFiniteError naming `model.set_gemm_precision('bf16x3')` (bf16 terms have fp32's exponent range). */
+enum {
+    LVAE_STATUS_RANGE = 1, LVAE_STATUS_NONFINITE_PRIOR = 2, LVAE_STATUS_NONFINITE_LATENT = 4, LVAE_STATUS_NONFINITE_IMAGE = 8
+};
+
 /* ------------------------------------------------------------------------------------------------ device kernels
  * GEMM family: out[m][n] = epilogue( sum_k A[m][k] * Wt[n][k] + bias[n] ), fp32 in / fp32 accumulate on
  * v_mfma_f32_32x32x2_f32.  Replaces timm Mlp fc1/fc2 (common.py:131-132,154), conv 1x1 (qarv/model.py:36,38,39;
@@ -147,6 +166,9 @@ typedef struct {
                                              every tile shape), ZERO before the first launch; each launch leaves them zero again.
                                              Non-NULL: the last slice workgroup of a tile to arrive reduces the S slabs in slice order
                                              inside the GEMM launch (no second kernel; same bits).  NULL: separate reduce launch */
+    int* status;                          /* optional device status word (LVAE_STATUS_* bits, above): the final-image store (ST_IMAGE) ORs
+                                             LVAE_STATUS_NONFINITE_IMAGE into it when a value is NaN / inf before the clamp (the clamp would
+                                             hide it).  NULL = no check */
     int  a_h2, out_h2;                    /* prec 4 only, "pre-split" operands in the f16x2 plane format H2K32 = [rows][K/32][2][32] fp16
                                              (per 32 k: 32 hi terms, then 32 lo' terms; a row is K*4 bytes like its fp32 form;
                                              lvae.models.base.pack_f16x2_k32): a_h2 = 1: A0 is such a buffer (PLAIN, K1 = 0, lda0 = K,
@@ -194,10 +216,16 @@ int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int
  * `block.decompress` calls, qarv/model.py:531-557; qresvae/model.py:446-454): for every latent block, in order --
  *   launch its plan segment (up to its prior / index kernel) -> copy its scale indexes to pinned host memory -> wait for the stream ->
  *   rANS-decode the block's n_images streams (lvae_rans_decode_batch) into pinned host memory -> copy the symbols to the device --
- * then launch the tail segment (no wait: the caller synchronises).  `strings` / `string_len` are block-major: entry b * n_images + i
- * is image i's stream of block b.  Index / symbol buffers hold n_images * per_image entries per block, image after image.
- * Returns 0, a launch error (failed_block = block, failed_op = index in its segment; block n_blocks = the tail), or -74 (EBADMSG) when a
- * stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional) receive the time spent waiting for the GPU
+ * then launch the tail segment (no wait: the caller synchronises).  `strings` / `string_len` are block-major: entry b * n_images + i is
+ * image i's stream of block b.  Index / symbol buffers hold n_images * per_image entries per block, image after image.
+ * `status_dev` / `status_host` (optional; status_host = one pinned int): the plan's status word (LVAE_STATUS_*) is copied ONCE, behind the
+ * tail (the per-block chain is latency-bound and carries no extra copy: scale indexes are valid table rows whatever the prior parameters
+ * were, so the coder cannot be hurt by them).  The CALLER reads *status_host after its own synchronisation and before it hands the
+ * reconstruction on: non-zero = non-finite prior parameters / reconstruction -- an fp16 overflow of the default arithmetic, or a stream
+ * written under another arithmetic.  A stream that fails to decode (-74) is reported as -75 (EOVERFLOW) when the word is set at that
+ * point (garbage indexes, not a corrupt stream).  The caller zeroes the device word again.
+ * Returns 0, a launch error (failed_block = block, failed_op = index in its segment; block n_blocks = the tail), -75 (above), or -74
+ * (EBADMSG) when a stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional) receive the time spent waiting for the GPU
  * segments and inside the coder. */
 typedef struct {
     const lvae_op* ops; int n_ops;
@@ -207,15 +235,19 @@ typedef struct {
 } lvae_dec_block;
 int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings, const size_t* string_len,
                        const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
-                       const lvae_op* tail_ops, int n_tail, void* stream, void* side_stream, int n_threads,
-                       int* failed_block, int* failed_op, double* seconds);
+                       const lvae_op* tail_ops, int n_tail, const int* status_dev, int* status_host, void* stream, void* side_stream,
+                       int n_threads, int* failed_block, int* failed_op, double* seconds);
 
 /* One pipeline group's ENCODE as a single foreign call (the loop around `block.compress`, qarv/model.py:516-529): launch every block's
  * segment (through its quantize kernel), each followed by the copies of its symbols / scale indexes to pinned host memory and an event;
  * then, block by block, wait for its event and rANS-encode its n_images streams (lvae_rans_encode_batch) into out[b * n_images + i]
  * (capacity out_cap[b * n_images + i]), while the GPU computes the later blocks.  out_len[b * n_images + i] receives the byte count.
- * `flag_dev` / `flag_host` (optional): the input-range flag of the stem kernel, copied after block 0; a non-zero flag returns -34 (ERANGE)
- * before anything is coded.  Events are created and destroyed inside the call. */
+ * `status_dev` / `status_host` (optional; status_host = one pinned int): the plan's status word (LVAE_STATUS_*), copied ONCE behind the last
+ * block's segment and checked before that block is coded: LVAE_STATUS_RANGE set returns -34 (ERANGE: the reference's input assert), any
+ * other bit -75 (EOVERFLOW: non-finite prior parameters / posterior means -- an fp16 overflow of the default arithmetic), with
+ * failed_block = n_blocks - 1; the strings of the earlier blocks are to be discarded (the coder accepts any int32 symbol, and every scale
+ * index is a valid table row, so coding them was harmless).  The caller zeroes the device word again.  Events are created and destroyed
+ * inside the call. */
 typedef struct {
     const lvae_op* ops; int n_ops;
     const int32_t* sym_dev; int32_t* sym_host;
@@ -224,7 +256,7 @@ typedef struct {
 } lvae_enc_block;
 int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap, long* out_len,
                        const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
-                       const int* flag_dev, int* flag_host, void* stream, void* side_stream, int n_threads,
+                       const int* status_dev, int* status_host, void* stream, void* side_stream, int n_threads,
                        int* failed_block, int* failed_op, double* seconds);
 
 /* Depthwise kxk conv (+bias) -> LayerNorm over C (eps 1e-6, biased variance, no affine) -> AdaLN
@@ -280,12 +312,14 @@ int lvae_gemv_f32(const float* Wt, const float* b, const float* x, float* y, int
  * index of every latent element in the coder's NCHW raster order idx[b][c][h][w] (uint8 0..n_scales-1):
  *   pv = exp(softplus(x+2.3)-2.3); s = max(pv, bound); idx = #{i < n_scales-1 : table[i] < s}. */
 int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
-                         float scale_bound, int B, int HW, int z, void* stream);
+                         float scale_bound, int B, int HW, int z, int* status, void* stream);
+/* status (optional): LVAE_STATUS_NONFINITE_PRIOR is OR-ed in when a mean or log-scale parameter is NaN / inf (see "status word"). */
 
 /* GaussianConditional.quantize (qarv/model.py:107-108): sym = int32(rint_half_even(qm - pm)) in NCHW raster order
  * per image, zhat = float(sym) + pm in NHWC (row stride ldz, see below). */
 int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
-                      void* stream);
+                      int* status, void* stream);
+/* status (optional): LVAE_STATUS_NONFINITE_LATENT is OR-ed in when qm - pm is NaN / inf or |rint(qm - pm)| >= 2^31. */
 /* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order.
  * In both, zhat rows have stride ldz >= z floats; columns [z, ldz) are written as zeros (lets a following 3x3 conv
  * consume a channel count rounded up to a multiple of 4: qres34m z = 14, 10). */
@@ -306,10 +340,12 @@ int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdim, int ldz,
  *   s   = exp(ls - ln(bin));  idx = #{i < n_scales-1 : table[i] < max(s, bound)}          (build_indexes)
  *   sym = rint(((im - 0.5)*2)/bin - pm)        only when im != NULL (encoder); im is (B,3,H,W) in [0,1]. */
 int lvae_lossless_params_f32(const float* raw, const float* im, float* pm, uint8_t* idx, int32_t* sym, const float* table,
-                             int n_scales, float bound, int B, int H, int W, void* stream);
+                             int n_scales, float bound, int B, int H, int W, int* status, void* stream);
+/* status (optional): LVAE_STATUS_NONFINITE_PRIOR when a mean / log-scale parameter is NaN / inf. */
 
 /* ... and its decoder side (:86-94 + process_output :496-504): out = clamp((sym + pm)*bin, -1, 1)*0.5 + 0.5, NCHW. */
-int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, void* stream);
+int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, int* status, void* stream);
+/* status (optional): LVAE_STATUS_NONFINITE_IMAGE when sym + pm is NaN / inf (the clamp would hide it). */
 
 /* Eval-mode rate estimate of one latent block (qarv/model.py:95-96 = CompressAI GaussianConditional.forward in eval mode):
  * out_nats[b] += sum over the block's elements of -ln max(P, 1e-9), P = Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s) in fp32 with

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/lvae_hip.h"
 #include "device_math.h"
 
@@ -18,6 +20,25 @@
 #endif
 
 namespace {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: a process that drives several GPUs (or a second device later on)
+// must set it on each of them, and the two pipeline-group threads may get here at the same time.  `done` is one bit per device ordinal
+// (a launcher-local static): set-once per device, lock-free, and setting it twice in a race is harmless.
+struct LdsAttr {
+    std::atomic<unsigned long long> done{0};
+    int ensure(const void* fn, int bytes, const void* fn2 = nullptr, int bytes2 = 0, const void* fn3 = nullptr, int bytes3 = 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return 0;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && fn2) e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes2);
+        if (e == hipSuccess && fn3) e = hipFuncSetAttribute(fn3, hipFuncAttributeMaxDynamicSharedMemorySize, bytes3);
+        if (e != hipSuccess) return (int)e;
+        done.fetch_or(bit, std::memory_order_release);
+        return 0;
+    }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -214,6 +235,7 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
             ccol[b] = ((long)sc * (d.H * rr) + si) * (d.W * rr) + sj;
         }
     }
+    bool bad = false;
 #pragma unroll
     for (int a = 0; a < C::TM; ++a) {
         const int rbase = m0 + (wave_m * C::TM + a) * 32 + 4 * lh;
@@ -237,11 +259,15 @@ __device__ __forceinline__ void gemm_epilogue(const lvae_gemm_desc& d, f32x16 (&
                 if (epi == LVAE_EPI_BIAS_GELU) v = gelu_erf(v);
                 else if (epi == LVAE_EPI_GAMMA_RES) v = resrow[ccol[b]] + cgam[b] * v;
                 else if (epi == LVAE_EPI_RES) v = resrow[ccol[b]] + v;
-                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                if (store == LVAE_ST_IMAGE) {
+                    bad |= !(fabsf(v) <= 3.4028234664e38f);      // NaN / inf: the clamp below would hide it (include/lvae_hip.h "status word")
+                    v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                }
                 d.out[obase + ccol[b]] = v;
             }
         }
     }
+    if (store == LVAE_ST_IMAGE && d.status && bad) atomicOr(d.status, LVAE_STATUS_NONFINITE_IMAGE);
 }
 
 // Split-K tail: out = epilogue(sum over slices IN SLICE ORDER of ws[s] + bias) for 16-B chunks of the output.  Shared by the in-kernel

@@ -532,21 +532,14 @@ template <class C, int AMODE>
 int launch_cfg(const lvae_gemm_desc* d, hipStream_t st) {
     const int tiles_m = (d->M + C::BM - 1) / C::BM, tiles_n = (d->N + C::BN - 1) / C::BN;
     const int n_tiles = tiles_m * tiles_n;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        if constexpr (C::BK == 32) {
-            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    C::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            e = hipFuncSetAttribute((const void*)gemm_x3_kernel<C, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (C::BM + C::BN) * 208);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    int ae;
+    if constexpr (C::BK == 32)
+        ae = attr.ensure((const void*)gemm_kernel<C, AMODE>, C::LDS_BYTES, (const void*)gemm_bf16_kernel<C, AMODE>, C::LDS_BYTES,
+                         (const void*)gemm_x3_kernel<C, AMODE>, (C::BM + C::BN) * 208);
+    else
+        ae = attr.ensure((const void*)gemm_kernel<C, AMODE>, C::LDS_BYTES);
+    if (ae) return ae;
     if constexpr (C::BK == 32) {
         if (d->prec == 1) {
             hipLaunchKernelGGL((gemm_bf16_kernel<C, AMODE>), dim3(n_tiles, ksp(d)), dim3(C::NT), C::LDS_BYTES, st, *d, tiles_n, n_tiles);
@@ -687,14 +680,16 @@ static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2,
 static int gemm_dispatch(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) { return gemm_dispatch_impl(d, st, x3v2, x3v2_tn); }
 
 extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
-    static bool env_read = false;
-    static int x3v2 = 1, x3v2_tn = 0;      // tuning hooks: LVAE_X3V2=0 keeps prec 2 on gemm_x3_kernel, LVAE_X3V2_TN forces its tile
-    if (!env_read) {
+    static int x3v2 = 1, x3v2_tn = 0;
+#ifdef LVAE_EXPERIMENTAL_BUILD             // tuning hooks of tools/build_exp.sh copies only (every choice gives the same bits; the product
+    static bool env_read = false;          // library's launch paths read no environment): LVAE_X3V2=0 keeps prec 2 on gemm_x3_kernel,
+    if (!env_read) {                       // LVAE_X3V2_TN forces its tile, LVAE_GEMM_CFG the legacy kernels' configuration
         const char* e = getenv("LVAE_GEMM_CFG"); if (e) g_force_cfg = atoi(e);
         e = getenv("LVAE_X3V2"); if (e) x3v2 = atoi(e);
         e = getenv("LVAE_X3V2_TN"); if (e) x3v2_tn = atoi(e);
         env_read = true;
     }
+#endif
     if (!d || !d->A0 || (!d->Wt && !(d->prec != 0 && d->Wt16)) || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0) return -22;
     if ((d->K & 3) || (d->ldw & 3)) return -22;                       // 16-B operand loads
     if (d->prec < 0 || d->prec > 4) return -22;
@@ -743,9 +738,15 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
 
 static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2, int x3v2_tn) {
     if (d->prec == 4) {                  // f16x2: one kernel family; the host asks for it only where it applies (engine.h2_eligible)
-        static int h2_tn = -1, h2p_tile = -1;
-        if (h2_tn < 0) { const char* e = getenv("LVAE_H2_TN"); h2_tn = e ? atoi(e) : 0; }
-        if (h2p_tile < 0) { const char* e = getenv("LVAE_H2P_TILE"); h2p_tile = e ? atoi(e) : 0; }
+        static int h2_tn = 0, h2p_tile = 0;
+#ifdef LVAE_EXPERIMENTAL_BUILD             // tile sweeps (tools/h2p_sweep.sh) on experimental builds only
+        static bool h2_env = false;
+        if (!h2_env) {
+            const char* e = getenv("LVAE_H2_TN"); h2_tn = e ? atoi(e) : 0;
+            e = getenv("LVAE_H2P_TILE"); h2p_tile = e ? atoi(e) : 0;
+            h2_env = true;
+        }
+#endif
         int rc = 0;
         if (d->out_h2 && (d->store != LVAE_ST_ROWMAJOR || (d->epi != LVAE_EPI_BIAS && d->epi != LVAE_EPI_BIAS_GELU) || (d->N & 31) ||
                           d->ldo != d->N || (d->ksplit > 1 && !d->a_h2)))

@@ -11,8 +11,12 @@
 // Measured on the reference goldens by CPU emulation of the split alone (tools/split_error_study.py): rms deviation of the prior /
 // posterior means from exact arithmetic 9.9e-7 (bf16x3: 5.7e-7; the REFERENCE's own fp32 accumulation: 2.6e-6), i.e. the expected
 // number of rounding flips against the reference rises by ~3 %.  Range: |x| must stay below 65504 (fp16); weights are checked when they
-// are packed, activations of this network are O(1..100) (LayerNorm-ed blocks) -- an overflow turns into inf/NaN in the prior parameters,
-// which lvae_prior_index_f32 reports through its flag (the caller then raises and names set_gemm_precision('bf16x3')).
+// are packed, activations of this network are O(1..100) (LayerNorm-ed blocks).  An activation >= 65520 becomes inf in its hi term, and an
+// inf / NaN stays one through every later MFMA sum, GELU, residual add and LayerNorm until it reaches one of the codec's sinks -- a prior
+// parameter, a posterior mean or the reconstruction -- where lvae_prior_index_f32 / lvae_quantize_f32 / the ST_IMAGE store OR a bit into
+// the plan's status word (include/lvae_hip.h "status word"); lvae_encode_blocks / lvae_decode_blocks read the word per latent block and
+// the Python host raises lvae.NonFiniteError naming set_gemm_precision('bf16x3') before any byte string or image is returned
+// (tests/test_gpu_overflow.py).
 //
 // Kernel.  Same software pipeline as gemm_x3k16_kernel (gemm_x3v2.hip: fenced filler slices in the MFMA shadows of the same wave,
 // double-buffered LDS with 16-deep stages, buffer loads with hardware range checks two stages ahead, k16-interleaved weights,

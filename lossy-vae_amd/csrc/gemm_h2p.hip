@@ -234,18 +234,19 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
 template <int WM, int TN, int NBUF, bool FOLD = false>
 int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * TN, LDS = NBUF * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, LDS)) return ae;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
-    static int lds_pad = -1;             // experiment knob: extra dynamic LDS (forces one 128-row workgroup per CU)
-    if (lds_pad < 0) { const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0; }
+    static int lds_pad = 0, stagger = 0;
+#ifdef LVAE_EXPERIMENTAL_BUILD           // knobs of the round-3 studies (tools/build_exp.sh copies only): extra dynamic LDS (forces
+    static bool env_read = false;        // one 128-row workgroup per CU) and the phase stagger (measured 0 ... -5 % on the model's shapes)
+    if (!env_read) {
+        const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0;
+        e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0;
+        env_read = true;
+    }
     if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
-    static int stagger = -1;             // experiment knob (default off: measured 0 ... -5 % on the model's shapes)
-    if (stagger < 0) { const char* e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0; }
+#endif
     hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF, FOLD>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
     return (int)hipGetLastError();
 }

@@ -441,7 +441,10 @@ __global__ __launch_bounds__(256, (TN <= 2 && ABF ? 3 : 2)) void gemm_lp_kernel(
                     const float rv = OBF ? __uint_as_float((unsigned)((const unsigned short*)d.res)[ro] << 16) : d.res[ro];
                     v = rv + gm * v;
                 }
-                if (store == LVAE_ST_IMAGE) v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                if (store == LVAE_ST_IMAGE) {
+                    if (d.status && !(fabsf(v) <= 3.4028234664e38f)) atomicOr(d.status, LVAE_STATUS_NONFINITE_IMAGE);   // the clamp would hide it
+                    v = fminf(fmaxf(v, -1.0f), 1.0f) * 0.5f + 0.5f;
+                }
                 if (OBF && store != LVAE_ST_IMAGE) ((unsigned short*)d.out)[obase + ccol] = f32_to_bf16(v);
                 else d.out[obase + ccol] = v;
             }
@@ -464,11 +467,13 @@ int launch_lp_tn(const lvae_gemm_desc* d, hipStream_t st) {
     // fp32 A (the K = z operands of z_proj): 64-wide tiles (its wider instances would spill); N a multiple of 192: 128 x 192 tiles
     // (N = 192 is ONE column tile: A is read once instead of twice, and no half-empty 128 x 128 tile)
     int tn = (d->N <= 64 || !ABF) ? 1 : ((d->N % 192 == 0) ? 3 : 2);
+#ifdef LVAE_EXPERIMENTAL_BUILD           // tile sweep hook (tools/build_exp.sh copies only)
     {
         static int force = -1;
         if (force < 0) { const char* e = getenv("LVAE_LP_TN"); force = e ? atoi(e) : 0; }
         if (force >= 1 && force <= 3 && ABF && d->N > 64) tn = force;
     }
+#endif
     if (tn == 1) return launch_lp<1, AMODE, ABF, OBF>(d, st);
     if constexpr (ABF) return tn == 3 ? launch_lp<3, AMODE, ABF, OBF>(d, st) : launch_lp<2, AMODE, ABF, OBF>(d, st);
     return -22;

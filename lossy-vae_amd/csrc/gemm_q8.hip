@@ -235,12 +235,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_q8_kernel(co
 template <int WM, int TN, int NBUF>
 int launch_q8(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * TN, LDS = NBUF * ((BM + BN) * 64 + 2048);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_q8_kernel<WM, TN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)gemm_q8_kernel<WM, TN, NBUF>, LDS)) return ae;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_q8_kernel<WM, TN, NBUF>), dim3(n_tiles), dim3(128 * WM), LDS, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();

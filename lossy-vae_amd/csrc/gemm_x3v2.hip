@@ -197,12 +197,8 @@ template <bool AGELU>
 int launch_w8(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int LDS = 2 * (256 + 128) * 208;
     static_assert(LDS <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3w8_kernel<AGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)gemm_x3w8_kernel<AGELU>, LDS)) return ae;
     const int tiles_m = (d->M + 255) / 256, tiles_n = (d->N + 127) / 128, n_tiles = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_x3w8_kernel<AGELU>), dim3(n_tiles), dim3(512), LDS, st, *d, tiles_n, n_tiles);
     return (int)hipGetLastError();
@@ -467,12 +463,8 @@ constexpr int g_x3v2_lds_pad = 0;
 template <int TN, bool AGELU, int AMODE>
 int launch_k16(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BN = 64 * TN, LDS = 2 * (128 + BN) * 112;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3k16_kernel<TN, AGELU, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 64 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)gemm_x3k16_kernel<TN, AGELU, AMODE>, LDS + 64 * 1024)) return ae;
     const int tiles_m = (d->M + 127) / 128, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_x3k16_kernel<TN, AGELU, AMODE>), dim3(n_tiles, d->ksplit > 1 ? d->ksplit : 1), dim3(256), LDS + g_x3v2_lds_pad, st, *d,
                        tiles_n, n_tiles);

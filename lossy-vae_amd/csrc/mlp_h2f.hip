@@ -255,12 +255,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
 extern "C" int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream) {
     if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || d->M <= 0) return -22;
     if (d->C != F_C || d->hid != F_HID) return -22;                    // the one block shape this kernel exists for
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_h2f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)mlp_h2f_kernel, F_LDS)) return ae;
     hipLaunchKernelGGL(mlp_h2f_kernel, dim3((d->M + F_BM - 1) / F_BM), dim3(512), F_LDS, (hipStream_t)stream, *d);
     return (int)hipGetLastError();
 }

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ Wt,
 // ------------------------------------------------------------------------------------------------ lossless output net
 __global__ void lossless_params_kernel(const float* __restrict__ raw, const float* __restrict__ im, float* __restrict__ pm,
                                        uint8_t* __restrict__ idx, int32_t* __restrict__ sym, const float* __restrict__ table,
-                                       int n_scales, float bound, long total, int HW) {
+                                       int n_scales, float bound, long total, int HW, int* __restrict__ status) {
 #pragma clang fp contract(off)
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = (b*3 + c)*HW + p   (NCHW raster)
     if (e >= total) return;
@@ -331,6 +331,7 @@ __global__ void lossless_params_kernel(const float* __restrict__ raw, const floa
     m = rintf(m) / 127.5f;
     m = m - 1.0f;
     m = m / bin;
+    if (status && !(fabsf(r[c]) <= 3.4028234664e38f && fabsf(r[3 + c]) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_PRIOR);
     const float ls = r[3 + c] - (float)(-4.848116360536466);        // - math.log(1/127.5)
     const float s = fmaxf(expf(ls), bound);
     int lo = 0, hi = n_scales - 1;
@@ -348,11 +349,13 @@ __global__ void lossless_params_kernel(const float* __restrict__ raw, const floa
     }
 }
 
-__global__ void lossless_output_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ out, long n) {
+__global__ void lossless_output_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ out, long n,
+                                       int* __restrict__ status) {
 #pragma clang fp contract(off)
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float x = (float)sym[e] + pm[e];
+    if (status && !(fabsf(x) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_IMAGE);
     x = x * (float)(1.0 / 127.5);
     x = fminf(fmaxf(x, -1.0f), 1.0f);
     x = x * 0.5f;
@@ -398,13 +401,17 @@ __global__ void prior_sample_kernel(const float* __restrict__ prm, float* __rest
 
 // ------------------------------------------------------------------------------------------------ entropy parameters
 __global__ void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
-                                   const float* __restrict__ table, int n_scales, float bound, long total, int HW, int z) {
+                                   const float* __restrict__ table, int n_scales, float bound, long total, int HW, int z,
+                                   int* __restrict__ status) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*z + c
     if (e >= total) return;
     const long m = e / z;
     const int c = (int)(e - m * z);
     const float mean = prm[m * 2 * z + c];
     const float lv = prm[m * 2 * z + z + c];
+    // a NaN / inf prior parameter (an fp16 overflow of the f16x2 arithmetic upstream, include/lvae_hip.h "status word") would become
+    // index 0 / 63 and a NaN mean silently: report it (one atomic per wave that saw one)
+    if (status && !(fabsf(mean) <= 3.4028234664e38f && fabsf(lv) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_PRIOR);
     // softplus(x + 2.3) - 2.3  (torch: beta=1, threshold=20)
     const float xs = lv + 2.3f;
     const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
@@ -423,7 +430,7 @@ __global__ void prior_index_kernel(const float* __restrict__ prm, float* __restr
 }
 
 __global__ void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
-                                float* __restrict__ zhat, long total, int HW, int z, int ldz) {
+                                float* __restrict__ zhat, long total, int HW, int z, int ldz, int* __restrict__ status) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*ldz + c over the PADDED rows
     if (e >= total) return;
     const long m = e / ldz;
@@ -431,6 +438,7 @@ __global__ void quantize_kernel(const float* __restrict__ qm, const float* __res
     if (c >= z) { zhat[e] = 0.f; return; }
     const float mu = pm[m * z + c];
     const float r = rintf(qm[m * z + c] - mu);  // v_rndne_f32: round-half-to-even == torch.round
+    if (status && !(fabsf(r) < 2147483648.0f)) atomicOr(status, LVAE_STATUS_NONFINITE_LATENT);      // NaN / inf / no int32 symbol
     zhat[e] = r + mu;
     const long b = m / HW;
     const int p = (int)(m - b * HW);
@@ -527,11 +535,13 @@ extern "C" int lvae_dwconv_ln_f32(const float* x, const float* wt, const float* 
         int rc = 0;
         if (lvae_dwln_cl_try(x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, C, k, 0, (hipStream_t)stream, &rc)) return rc;
     }
+#ifdef LVAE_EXPERIMENTAL_BUILD           // tile-height sweep hook (tools/build_exp.sh copies only)
     static bool env_read = false;
     if (!env_read) {
         const char* e = getenv("LVAE_DW_TH"); if (e) g_dw_th = atoi(e);
         env_read = true;
     }
+#endif
     hipStream_t st = (hipStream_t)stream;
     switch (k) {
         case 1: return dispatch_dwln_c<1>(C, x, wt, bias, ln_w, ln_b, shift, scale1p, y, B, H, W, st);
@@ -641,20 +651,20 @@ extern "C" int lvae_gemv_f32(const float* Wt, const float* b, const float* x, fl
 }
 
 extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
-                                    float scale_bound, int B, int HW, int z, void* stream) {
+                                    float scale_bound, int B, int HW, int z, int* status, void* stream) {
     if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || HW <= 0 || z <= 0) return -22;
     const long total = (long)B * HW * z;
     hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prm, pm,
-                       idx, scale_table, n_scales, scale_bound, total, HW, z);
+                       idx, scale_table, n_scales, scale_bound, total, HW, z, status);
     return (int)hipGetLastError();
 }
 
 extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
-                                 void* stream) {
+                                 int* status, void* stream) {
     if (!qm || !pm || !sym || !zhat || B <= 0 || HW <= 0 || z <= 0 || ldz < z) return -22;
     const long total = (long)B * HW * ldz;
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
-                       zhat, total, HW, z, ldz);
+                       zhat, total, HW, z, ldz, status);
     return (int)hipGetLastError();
 }
 
@@ -742,17 +752,17 @@ extern "C" int lvae_prior_sample_f32(const float* prm, float* z, long M, int zdi
 }
 
 extern "C" int lvae_lossless_params_f32(const float* raw, const float* im, float* pm, uint8_t* idx, int32_t* sym, const float* table,
-                                        int n_scales, float bound, int B, int H, int W, void* stream) {
+                                        int n_scales, float bound, int B, int H, int W, int* status, void* stream) {
     if (!raw || !pm || !idx || !table || n_scales <= 0 || n_scales > 256 || B <= 0 || H <= 0 || W <= 0 || (im && !sym)) return -22;
     const long total = (long)B * 3 * H * W;
     hipLaunchKernelGGL(lossless_params_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, im, pm,
-                       idx, sym, table, n_scales, bound, total, H * W);
+                       idx, sym, table, n_scales, bound, total, H * W, status);
     return (int)hipGetLastError();
 }
 
-extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, void* stream) {
+extern "C" int lvae_lossless_output_f32(const int32_t* sym, const float* pm, float* out, long n, int* status, void* stream) {
     if (!sym || !pm || !out || n <= 0) return -22;
-    hipLaunchKernelGGL(lossless_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm, out, n);
+    hipLaunchKernelGGL(lossless_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm, out, n, status);
     return (int)hipGetLastError();
 }
 
@@ -771,5 +781,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 18; }
+extern "C" int lvae_abi_version(void) { return 19; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -256,6 +256,16 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
 }
 
 namespace {
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 // Persistent worker pool.  The coder is called 2 x (1 + 9) times per batch by two pipeline-group threads; spawning up to 35
 // std::threads per call put ~0.5-1 ms of thread creation on each call and made step times jittery.  Jobs are index ranges
 // [0, n) claimed with an atomic counter; callers take part in their own job and several callers may have jobs in flight.
@@ -297,16 +307,23 @@ private:
             std::shared_ptr<Job> j;
             if (spinner) {
                 const unsigned seen = epoch_.load(std::memory_order_acquire);
-                for (int it = 0; it < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++it) __builtin_ia32_pause();
+                for (int it = 0; it < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++it) cpu_relax();
             }
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [this] { return !q_.empty(); });
-                j = q_.front();
-                if (j->next.load() >= j->n || j->workers.load() >= j->max_workers) { q_.pop_front(); continue; }
-                j->workers.fetch_add(1);
+                // retire exhausted / saturated jobs at the front and take the first one that still wants a worker -- in ONE pass under the
+                // lock: going back to the spin after retiring a job (as this loop once did) left a second pipeline group's job, already
+                // queued behind it, without helpers for a whole spin period (~0.5 ms on the per-block calls of the decode chain)
+                while (!q_.empty()) {
+                    const std::shared_ptr<Job>& f = q_.front();
+                    if (f->next.load() >= f->n || f->workers.load() >= f->max_workers) { q_.pop_front(); continue; }
+                    j = f;
+                    j->workers.fetch_add(1);
+                    break;
+                }
             }
-            work(*j);
+            if (j) work(*j);
         }
     }
 public:
@@ -336,7 +353,7 @@ void parallel_for(int n, int n_threads, F&& f) {
     j->run = [](void* c, int i) { (*(typename std::remove_reference<F>::type*)c)(i); };
     Pool::get().submit(j);
     Pool::work(*j);
-    for (int it = 0; it < 20000 && j->done.load(std::memory_order_acquire) < n; ++it) __builtin_ia32_pause();   // the stragglers are usually microseconds away
+    for (int it = 0; it < 20000 && j->done.load(std::memory_order_acquire) < n; ++it) cpu_relax();   // the stragglers are usually microseconds away
     std::unique_lock<std::mutex> l(j->m);
     j->cv.wait(l, [&] { return j->done.load() >= n; });
 }

@@ -3,3 +3,4 @@ encode/decode path: get_model / compress_mode / compress / decompress / compress
 from .paths import known_datasets
 from .models.registry import get_model
 from . import models
+from .engine import NonFiniteError

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
         ('a_gelu', C.c_int), ('prec', C.c_int), ('Wt16', C.c_void_p), ('cfg', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('a_bf16', C.c_int), ('out_bf16', C.c_int), ('cnt', C.c_void_p),
-        ('a_h2', C.c_int), ('out_h2', C.c_int),
+        ('status', C.c_void_p), ('a_h2', C.c_int), ('out_h2', C.c_int),
     ]
 
 
@@ -61,6 +61,7 @@ OP_KINDS = {name: k + 1 for k, name in enumerate([
 OP_ORDER = len(OP_KINDS) + 1
 
 A_PLAIN, A_PATCH2, A_CONV3 = 0, 1, 2
+STATUS_RANGE, STATUS_NONFINITE_PRIOR, STATUS_NONFINITE_LATENT, STATUS_NONFINITE_IMAGE = 1, 2, 4, 8      # LVAE_STATUS_* (status word)
 EPI_BIAS, EPI_BIAS_GELU, EPI_GAMMA_RES, EPI_RES = 0, 1, 2, 3
 ST_ROWMAJOR, ST_SHUFFLE, ST_IMAGE = 0, 2, 3
 
@@ -88,11 +89,11 @@ SIGNATURES = {
     'lvae_stem_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'lvae_bias_expand_bf16': (_i, [_vp, _vp, _l, _i, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
-    'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
+    'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'lvae_lossless_params_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
-    'lvae_lossless_output_f32': (_i, [_vp, _vp, _vp, C.c_long, _vp]),
+    'lvae_lossless_params_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
+    'lvae_lossless_output_f32': (_i, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
     'lvae_prior_sample_f32': (_i, [_vp, _vp, C.c_long, _i, _i, C.c_float, C.c_ulonglong, C.c_ulonglong, _vp]),
     'lvae_gaussian_nll_f32': (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     'lvae_bias_expand_f32': (_i, [_vp, _vp, _l, _i, _vp]),
@@ -100,7 +101,7 @@ SIGNATURES = {
     'lvae_event_destroy': (_i, [_vp]),
     'lvae_stream_order': (_i, [_vp, _vp, _vp]),
     'lvae_run_ops': (_i, [_vp, _i, _vp, _vp, _vp]),
-    'lvae_decode_blocks': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'lvae_decode_blocks': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'lvae_encode_blocks': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'lvae_sqerr_sum_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'lvae_sqerr_partials_f32': (_i, [_vp, _vp, _vp, _i, _l, _vp]),

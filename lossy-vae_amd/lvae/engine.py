@@ -105,6 +105,25 @@ def h2_eligible(d):
 _ORDER = object()        # marker of a stream-ordering entry in Plan.ops
 
 
+class NonFiniteError(ArithmeticError):
+    """A NaN / inf reached one of the codec's sinks (prior parameters, posterior means / symbols, the reconstruction): nothing is
+    returned.  The reference computes its 1x1 convs and MLPs in fp32 (common.py:154, qarv/model.py:36-39); under the default 'f16x2'
+    arithmetic of this package an activation of 65520 or more overflows fp16 (csrc/gemm_h2.hip), which is what this error usually
+    means -- `model.set_gemm_precision('bf16x3')` (same accuracy class, fp32's exponent range) on BOTH the encoding and the decoding
+    side avoids it.  On decode it also fires for a stream written under another arithmetic or by other weights."""
+
+    def __init__(self, word, prec=None, where=''):
+        names = [n for bit, n in ((_native.STATUS_NONFINITE_PRIOR, 'prior parameters'), (_native.STATUS_NONFINITE_LATENT, 'posterior mean / symbols'),
+                                  (_native.STATUS_NONFINITE_IMAGE, 'reconstruction')) if word & bit]
+        self.word = word
+        hint = ("under the default 'f16x2' GEMM arithmetic this is an activation beyond fp16's range (>= 65520): call "
+                "model.set_gemm_precision('bf16x3') on the encoding AND the decoding side" if prec in (None, 'f16x2') else
+                f"GEMM arithmetic {prec!r}: the weights / inputs produce values outside the arithmetic's range")
+        super().__init__(f"non-finite values (NaN / inf) in {', '.join(names) or 'the codec'}{' ' + where if where else ''}; nothing was "
+                         f"returned.  {hint} (a stream decoded under another arithmetic or with other weights than it was written with "
+                         f"fails the same way)")
+
+
 class _EventHolder:
     def __init__(self, lib, ev):
         self.lib, self.ev = lib, ev
@@ -159,25 +178,36 @@ class Plan:
         self.keep.append(t)
         return t
 
-    # ---- input contract (reference: `assert 0 <= im.min() <= im.max() <= 1`, qarv/model.py:219-220, qresvae/model.py:492)
-    def alloc_range_flag(self):
-        """Device flag the stem kernel ORs a 1 into when it meets a pixel outside [0, 1] (or NaN) + its pinned host mirror."""
-        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        return self.range_flag.data_ptr()
+    # ---- the plan's status word (include/lvae_hip.h "status word"): one device int the stem kernel (input range, the reference's
+    # `assert 0 <= im.min() <= im.max() <= 1`, qarv/model.py:219-220, qresvae/model.py:492) and the codec's sinks -- prior parameters,
+    # posterior means / symbols, the final image store -- OR their LVAE_STATUS_* bits into.  It is zero unless something went wrong, so
+    # it is zeroed when allocated and after a raise only, never per call.
+    def status_ptr(self):
+        """Address of the plan's device status word (allocated on first use, with its pinned host mirror)."""
+        if getattr(self, 'status', None) is None:
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self.status.data_ptr()
 
-    def fetch_range_flag(self):
-        """Queue the 4-byte D2H copy of the flag on the current stream (call after the stem launch, before a sync/event)."""
-        if getattr(self, 'range_flag', None) is not None:
-            self.flag_host.copy_(self.range_flag, non_blocking=True)
+    def fetch_status(self):
+        """Queue the 4-byte D2H copy of the status word on the current stream (before a sync / event the caller has anyway)."""
+        if getattr(self, 'status', None) is not None:
+            self.status_host.copy_(self.status, non_blocking=True)
 
-    def raise_if_out_of_range(self):
-        """After a synchronisation that covers fetch_range_flag(): raise like the reference's preprocess_input assert."""
-        if getattr(self, 'range_flag', None) is not None and int(self.flag_host[0]) != 0:
-            self.range_flag.zero_()
-            self.flag_host.zero_()
+    def raise_if_flagged(self, word=None, where=''):
+        """After a synchronisation that covers fetch_status() (or with the word a native group loop returned): raise like the
+        reference's preprocess_input assert for an out-of-range input, NonFiniteError for a NaN / inf that reached a sink."""
+        if getattr(self, 'status', None) is None:
+            return
+        w = int(self.status_host[0]) if word is None else int(word)
+        if w == 0:
+            return
+        self.status.zero_()
+        self.status_host.zero_()
+        if w & _native.STATUS_RANGE:
             raise AssertionError('input image values must lie in [0, 1] (reference: preprocess_input, '
                                  '`0 <= im.min() <= im.max() <= 1`)')
+        raise NonFiniteError(w, getattr(self, 'prec_name', None), where)
 
     # ---- recording
     def add(self, fn, args, label=''):
@@ -285,6 +315,7 @@ class Plan:
         d.out, d.ldo = out, (ldo if ldo is not None else N)
         d.M, d.N, d.K = M, N, K
         d.a_mode, d.epi, d.store, d.r = a_mode, epi, store, r
+        d.status = self.status_ptr() if store == _native.ST_IMAGE else None      # a NaN / inf would pass the final clamp unseen
         d.cfg = 0
         d.a_gelu = a_gelu
         # bf16 / bf16x3 only when the plan provides the bf16 planes; exact=True forces the fp32 MFMA (pure data-movement GEMMs with

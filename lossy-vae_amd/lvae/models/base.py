@@ -230,11 +230,16 @@ class CodecBase(nn.Module):
         """Called by compress_mode(): one log line per model and mode naming the arithmetic its bitstreams are tied to."""
         if getattr(self, '_prec_logged', None) != self._prec:
             self._prec_logged = self._prec
-            _log.info('lvae: %s codes with GEMM arithmetic %r%s -- decode with the same mode', type(self).__name__, self._prec,
-                      ' (package default)' if self._prec == DEFAULT_PRECISION else ' (set explicitly)')
+            # WARNING level: the container (the reference's, byte for byte) does not record the arithmetic, and a stream decoded under
+            # another one fails -- with lvae.NonFiniteError at best, as a wrong picture at worst.  Builds before round 3 defaulted to 'bf16x3'.
+            _log.warning("lvae: %s codes with GEMM arithmetic %r%s; a bitstream decodes only under the arithmetic that wrote it "
+                         "(streams of builds that defaulted to 'bf16x3' need model.set_gemm_precision('bf16x3') on this side too)",
+                         type(self).__name__, self._prec, ' (package default)' if self._prec == DEFAULT_PRECISION else ' (set explicitly)')
 
     # ---- one pipeline group's decode / encode as ONE foreign call (csrc/plan_runtime.cpp: lvae_decode_blocks / lvae_encode_blocks)
     native_group_loops = os.environ.get('LVAE_PY_GROUP_LOOP') != '1'        # debugging / A-B switch: '1' = the per-block Python loops
+    status_checks = os.environ.get('LVAE_NO_STATUS_CHECK') != '1'           # A-B switch of tools/ab_status.sh ONLY: '1' = the group loops run
+                                                                            # without the status word (what the non-finite guard costs)
 
     @staticmethod
     def _group_blocks(pl, kind, cuts, offs, n):
@@ -274,10 +279,15 @@ class CodecBase(nn.Module):
         fb, fo = ctypes.c_int(-1), ctypes.c_int(-1)
         secs = (ctypes.c_double * 2)()
         ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
+        st_dev = pl.status_ptr() if self.status_checks else None
         with torch.cuda.device(pl.device):
             rc = _native.lib().lvae_decode_blocks(arr, nb, n, sp, sl, qcdf.ctypes.data, qcdf.shape[1], cdf_len.ctypes.data, offset.ctypes.data,
-                                                  ctypes.cast(tail, ctypes.c_void_p) if n_tail else None, n_tail, ctypes.c_void_p(stream.cuda_stream),
+                                                  ctypes.cast(tail, ctypes.c_void_p) if n_tail else None, n_tail, st_dev, pl.status_host.data_ptr(),
+                                                  ctypes.c_void_p(stream.cuda_stream),
                                                   ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
+        if rc == -75:           # a stream that did not decode because its scale indexes came from NaN / inf prior parameters
+            stream.synchronize()
+            pl.raise_if_flagged(int(pl.status_host[0]), where=f'while decoding (latent block {fb.value} of {nb})')
         if rc == -74:
             raise ValueError(f'rANS decode failed in latent block {fb.value} (corrupt or truncated bitstream)')
         if rc != 0:
@@ -302,15 +312,14 @@ class CodecBase(nn.Module):
         fb, fo = ctypes.c_int(-1), ctypes.c_int(-1)
         secs = (ctypes.c_double * 3)()
         ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
-        flag_dev = pl.range_flag.data_ptr() if getattr(pl, 'range_flag', None) is not None else None
-        flag_host = pl.flag_host.data_ptr() if flag_dev is not None else None
+        st_dev = pl.status_ptr() if self.status_checks else None
         with torch.cuda.device(pl.device):
             rc = _native.lib().lvae_encode_blocks(arr, nb, n, op, oc, out_len, qcdf.ctypes.data, qcdf.shape[1], cdf_len.ctypes.data, offset.ctypes.data,
-                                                  flag_dev, flag_host, ctypes.c_void_p(stream.cuda_stream),
+                                                  st_dev, pl.status_host.data_ptr(), ctypes.c_void_p(stream.cuda_stream),
                                                   ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
-        if rc == -34:
-            pl.raise_if_out_of_range()
-            raise ValueError('input image values must lie in [0, 1]')
+        if rc in (-34, -75):    # out-of-range input (the reference's assert) / NaN or inf in a prior parameter or posterior mean
+            pl.raise_if_flagged(int(pl.status_host[0]), where='while encoding')
+            raise RuntimeError(f'native encode reported rc={rc} without a status word')
         if rc != 0:
             raise RuntimeError(f'native encode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
         if T is not None:
@@ -318,6 +327,23 @@ class CodecBase(nn.Module):
             T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + secs[1]
             T['enc_rans'] = T.get('enc_rans', 0) + secs[2]
         return [[outs[li * n + b][:out_len[li * n + b]].tobytes() for b in range(n)] for li in range(nb)]
+
+    def _check_decoded(self, groups, plan_of):
+        """decompress_batch's last step: every group's decode has been queued (its status word travels to pinned memory behind its
+        tail segment); wait for the caller's stream -- which waits for the groups' -- and raise if a NaN / inf reached a prior
+        parameter or the reconstruction.  The reference's protocol synchronises right after decompress() anyway
+        (scripts/speedtest-lvae.py:34-36), so this costs nothing there; the reconstruction is never handed on unchecked."""
+        if not self.status_checks:
+            return
+        torch.cuda.current_stream(self._dummy.device).synchronize()
+        err = None
+        for g, (_start, n) in enumerate(groups):
+            try:
+                plan_of(g, n).raise_if_flagged(where='while decoding')
+            except ArithmeticError as e:                   # clear every group's word before raising
+                err = err or e
+        if err is not None:
+            raise err
 
     # ---- test access (not on the hot path)
     @torch.no_grad()
@@ -331,11 +357,9 @@ class CodecBase(nn.Module):
         for li, cut in enumerate(pl.qcuts):
             pl.run(lo, cut)
             lo = cut
-            if li == 0:
-                pl.fetch_range_flag()
+            pl.fetch_status()
             torch.cuda.synchronize(pl.device)
-            if li == 0:
-                pl.raise_if_out_of_range()
+            pl.raise_if_flagged(where=f'(encode trace, latent block {li})')
             z, hw = pl.lat_shapes[li]
             M, o = B * hw, pl.sym_off[li]
             prm = pl.prm_bufs[li][:M * 2 * z].view(B, hw, 2 * z)

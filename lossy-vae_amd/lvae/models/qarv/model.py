@@ -214,6 +214,7 @@ class _NetPlan(Plan):
         super().__init__(pk.adaln.device)
         self.model, self.pk, self.B = model, pk, B
         self.prec = PREC_CODE[model._prec]
+        self.prec_name = model._prec
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
         self.w16_k32 = pk.bf16_map('f16x2k32') if self.prec == 4 else None
@@ -288,7 +289,7 @@ class _NetPlan(Plan):
         self.lat_shapes.append((z, H * W))
         self.idx_off.append(ioff)
         self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
-                                            pk.scale_table.numel(), pk.scale_bound, B, H * W, z), p + '.prior_index')
+                                            pk.scale_table.numel(), pk.scale_bound, B, H * W, z, self.status_ptr()), p + '.prior_index')
         self.side_end()
         return pm, ioff
 
@@ -340,7 +341,7 @@ class _EncPlan(_NetPlan):
                 h, w = h // 4, w // 4
                 x = self.new(B * h * w * m.out_channels, self.adt)
                 self.add(lib.lvae_stem_bf16 if self.lp else lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
-                                             m.out_channels, model.im_shift, model.im_scale, self.alloc_range_flag()), p + '.stem')
+                                             m.out_channels, model.im_shift, model.im_scale, self.status_ptr()), p + '.stem')
                 self.flops += 2 * B * h * w * m.out_channels * 48
             elif m.kind == 'down':
                 h, w = h // 2, w // 2
@@ -394,7 +395,7 @@ class _EncPlan(_NetPlan):
                 self.qm_bufs.append(qm); self.zhat_bufs.append(zhat); self.zhat_ld.append(z)
                 self.sym_off.append(ioff)
                 self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
-                                                 B, h * w, z, z), p + '.quantize')
+                                                 B, h * w, z, z, self.status_ptr()), p + '.quantize')
                 self.qcuts.append(len(self.ops))        # this block's symbols and indexes are final from here on
                 if with_bits:       # eval-mode likelihood of the quantised latent (qarv/model.py:95-96), prm still holds this block
                     li = len(self.sym_off) - 1
@@ -621,8 +622,8 @@ class VariableRateLossyVAE(CodecBase):
                 o, cnt = pl.sym_off[li], n * z * hw
                 pl.sym_host[o:o + cnt].copy_(pl.sym_all[o:o + cnt], non_blocking=True)
                 pl.idx_host[o:o + cnt].copy_(pl.idx_all[o:o + cnt], non_blocking=True)
-                if li == 0:
-                    pl.fetch_range_flag()
+                if li == len(pl.qcuts) - 1:
+                    pl.fetch_status()
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 evs.append(ev)
@@ -631,12 +632,12 @@ class VariableRateLossyVAE(CodecBase):
             t1 = time.time()
             nl = len(pl.lat_shapes)
             per_block, t_wait = [], 0.0
+            evs[-1].synchronize()       # (debug loop: the status word is read once, behind the last block -- no progressive hand-over)
+            pl.raise_if_flagged(where='while encoding')
             for li, ev in enumerate(evs):
                 tw = time.time()
                 ev.synchronize()
                 t_wait += time.time() - tw
-                if li == 0:
-                    pl.raise_if_out_of_range()
                 z, hw = pl.lat_shapes[li]
                 o = pl.sym_off[li]
                 sv = [pl.sym_np[o + b * z * hw:o + (b + 1) * z * hw] for b in range(n)]
@@ -724,12 +725,14 @@ class VariableRateLossyVAE(CodecBase):
                     T['dec_gpu_seg'] = T.get('dec_gpu_seg', 0) + t1 - t0
                     T['dec_rans'] = T.get('dec_rans', 0) + t2 - t1
             pl.run(lo, None, stream=stream.cuda_stream)
+            pl.fetch_status()                               # read by _check_decoded() after the groups have finished
             out[start:start + n].copy_(pl.out, non_blocking=True)
             return None
 
         if T is not None:
             t_g = time.time()
         self._run_groups(decode_group, groups)
+        self._check_decoded(groups, lambda g, n: self._plan('dec', n, nH, nW, g))
         if T is not None:
             T['dec_groups_total'] = T.get('dec_groups_total', 0) + time.time() - t_g
             T['dec_calls'] = T.get('dec_calls', 0) + 1
@@ -801,12 +804,15 @@ class VariableRateLossyVAE(CodecBase):
         enc.im.view(B, 3, H, W).copy_(im)
         enc.nats.zero_()
         enc.run()
-        enc.fetch_range_flag()
+        enc.fetch_status()
         torch.cuda.current_stream(enc.device).synchronize()
-        enc.raise_if_out_of_range()
+        enc.raise_if_flagged(where='in estimate() (encoder)')
         # the encoder stops at CompresionStopFlag; reconstruct by feeding its symbols to the decode plan (same latent layout)
         dec.sym_all.copy_(enc.sym_all)
         dec.run()
+        dec.fetch_status()
+        torch.cuda.current_stream(dec.device).synchronize()
+        dec.raise_if_flagged(where='in estimate() (decoder)')
         return dec.out.clone(), enc.nats.view(self.num_latents, B).clone()
 
     @torch.no_grad()
@@ -856,6 +862,14 @@ class VariableRateLossyVAE(CodecBase):
                 if return_latents:
                     used.append(latents[li])
         pl.run(lo, None)
+        pl.fetch_status()
+        torch.cuda.current_stream(pl.device).synchronize()
+        if all(z is not None for z in latents) or float(t) == 0.0:
+            pl.raise_if_flagged(where='in conditional_sample()')
+        else:
+            # latents drawn from the prior at t > 0 are random numbers of the model's own scale (with untrained weights the deeper blocks'
+            # prior scales are astronomically large): whatever they lead to is the sample, as in the reference -- clear the word, no error
+            pl.status.zero_(); pl.status_host.zero_()
         return (pl.out.clone(), used) if return_latents else pl.out.clone()
 
     @torch.no_grad()
@@ -935,9 +949,9 @@ class VariableRateLossyVAE(CodecBase):
         if full or force_z is not None:
             return self._trace_blocks(pl, B, force_z)
         pl.run()
-        pl.fetch_range_flag()
+        pl.fetch_status()
         torch.cuda.current_stream(pl.device).synchronize()
-        pl.raise_if_out_of_range()
+        pl.raise_if_flagged(where='(encode trace)')
         sym, idx = pl.sym_all.cpu().numpy(), pl.idx_all.cpu().numpy()
         out = []
         h, w = H // 64, W // 64

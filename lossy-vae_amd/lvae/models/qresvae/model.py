@@ -258,6 +258,7 @@ class _QresPlan(Plan):
         if model._prec == 'fp8':
             raise NotImplementedError("the 'fp8' mode (bf16 activation storage + MX-fp8 GEMMs, BASELINE config 5) is built for qarv_base")
         self.prec = PREC_CODE[model._prec]
+        self.prec_name = model._prec
         self.w16 = pk.bf16_map(model._prec) if self.prec else None
         self.w16_x3 = pk.bf16_map('bf16x3') if self.prec == 4 else None
         self.w16_k32 = pk.bf16_map('f16x2k32') if self.prec == 4 else None
@@ -286,7 +287,7 @@ class _QresPlan(Plan):
                     h, w = h // 4, w // 4
                     x = self.new(B * h * w * m.out_channels)
                     self.add(lib.lvae_stem_f32, (self.im.data_ptr(), pk.p(p + '.w'), pk.p(p + '.b'), x.data_ptr(), B, H, W,
-                                                 m.out_channels, model.im_shift, model.im_scale, self.alloc_range_flag()), p + '.stem')
+                                                 m.out_channels, model.im_shift, model.im_scale, self.status_ptr()), p + '.stem')
                 elif m.kind == 'cnx':
                     self.cnx(p, m, x.data_ptr(), x.data_ptr(), h, w)
                 else:           # CNX out of place (x is this level's encoder feature), then 2x2/s2 conv
@@ -348,13 +349,13 @@ class _QresPlan(Plan):
             ioff = sum(a * b for a, b in self.lat_shapes) * B
             self.lat_shapes.append((z, h * w)); self.idx_off.append(ioff); self.sym_off.append(ioff)
             self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
-                                                pk.scale_table.numel(), pk.scale_bound, B, h * w, z), p + '.prior_index')
+                                                pk.scale_table.numel(), pk.scale_bound, B, h * w, z, self.status_ptr()), p + '.prior_index')
             zhat = self.buf('zhat', M * zp)
             self.prm_bufs.append(prm); self.zhat_bufs.append(zhat); self.zhat_ld.append(zp)
             if encode:
                 qm = self.buf('qm', M * z)
                 self.vdblock(p + '.posterior', m.posterior, f.data_ptr(), feats[h].data_ptr(), qm.data_ptr(), h, w)
-                self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(), B, h * w, z, zp),
+                self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(), B, h * w, z, zp, self.status_ptr()),
                          p + '.quantize')
                 self.qm_bufs.append(qm)
                 self.qcuts.append(len(self.ops))
@@ -377,6 +378,7 @@ class _QresPlan(Plan):
             Ho, Wo = h * on.rate, w * on.rate
             assert (Ho, Wo) == (H, W)
             raw = self.new(B * Ho * Wo * 6)
+            self.px_raw = raw                               # test access: conv_mean | conv_scale after PixelShuffle, NHWC [B*H*W][6]
             self.gemm(A0=f.data_ptr(), K0=on.cin, M=B * h * w, N=6 * on.rate ** 2, Wt=pk.p('out_net.w'), bias=pk.p('out_net.b'),
                       out=raw.data_ptr(), store=_native.ST_SHUFFLE, r=on.rate, H=h, W=w, label='out_net.conv')
             npx = B * 3 * H * W
@@ -388,11 +390,11 @@ class _QresPlan(Plan):
             self.add(lib.lvae_lossless_params_f32, (raw.data_ptr(), self.im.data_ptr() if encode else None, self.px_pm.data_ptr(),
                                                     self.px_idx.data_ptr(), self.px_sym.data_ptr() if encode else None,
                                                     pk.out_scale_table.data_ptr(), pk.out_scale_table.numel(), pk.out_scale_bound,
-                                                    B, H, W), 'out_net.params')
+                                                    B, H, W, self.status_ptr()), 'out_net.params')
             if not encode:
                 self.cuts.append(len(self.ops))
                 out = self.new(npx)
-                self.add(lib.lvae_lossless_output_f32, (self.px_sym.data_ptr(), self.px_pm.data_ptr(), out.data_ptr(), npx), 'out_net.output')
+                self.add(lib.lvae_lossless_output_f32, (self.px_sym.data_ptr(), self.px_pm.data_ptr(), out.data_ptr(), npx, self.status_ptr()), 'out_net.output')
                 self.out = out.view(B, 3, H, W)
         if not encode:
             assert self.out is not None
@@ -544,9 +546,9 @@ class HierarchicalVAE(CodecBase):
             if pl.lossless:
                 pl.px_sym_host.copy_(pl.px_sym, non_blocking=True)
                 pl.px_idx_host.copy_(pl.px_idx, non_blocking=True)
-            pl.fetch_range_flag()
+            pl.fetch_status()
             stream.synchronize()
-            pl.raise_if_out_of_range()
+            pl.raise_if_flagged(where='while encoding')      # out-of-range input / NaN or inf in a prior parameter or posterior mean
             sv, iv = [], []
             for b in range(n):
                 for li, (z, hw) in enumerate(pl.lat_shapes):
@@ -623,9 +625,11 @@ class HierarchicalVAE(CodecBase):
                 rans_decode_streams(tables, [objs[start + b][li][0] for b in range(n)], iv, sv, nthreads)
                 pl.sym_all[o:o + cnt].copy_(pl.sym_host[o:o + cnt], non_blocking=True)
             pl.run(lo, None, stream=stream.cuda_stream)
+            pl.fetch_status()                               # read by _check_decoded() after the groups have finished
             out[start:start + n].copy_(pl.out, non_blocking=True)
 
         self._run_groups(decode_group, groups)
+        self._check_decoded(groups, lambda g, n: self._plan('dec', n, H, W, g))
         return out
 
     @torch.no_grad()
@@ -688,9 +692,9 @@ class HierarchicalVAE(CodecBase):
         if full or force_z is not None:
             return self._trace_blocks(pl, B, force_z)
         pl.run()
-        pl.fetch_range_flag()
+        pl.fetch_status()
         torch.cuda.current_stream(pl.device).synchronize()
-        pl.raise_if_out_of_range()
+        pl.raise_if_flagged(where='(encode trace)')
         sym, idx = pl.sym_all.cpu().numpy(), pl.idx_all.cpu().numpy()
         return [dict(symbols=sym[o:o + B * z * hw].reshape(B, z, hw).copy(), indexes=idx[o:o + B * z * hw].reshape(B, z, hw).copy())
                 for o, (z, hw) in zip(pl.sym_off, pl.lat_shapes)]
@@ -720,4 +724,7 @@ class HierarchicalVAE(CodecBase):
             lo = cut + 1                                 # the launch at `cut` is this block's dequantize: skipped
         assert not pl.lossless, 'cond_sample: lossy models only (the lossless output net codes pixels, not a latent)'
         pl.run(lo, None)
+        pl.fetch_status()
+        torch.cuda.current_stream(pl.device).synchronize()
+        pl.raise_if_flagged(where='in cond_sample()')
         return pl.out.clone()

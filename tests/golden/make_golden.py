@@ -19,6 +19,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get('LVAE_GOLDEN_OUT', HERE)          # where the fixtures are written (default: next to this script)
 sys.path.insert(0, HERE)
 import ref_shims  # noqa: E402
 
@@ -73,7 +74,7 @@ def golden_cnx_block():
         y = blk(x, emb)
         out[f'{tag}.x'], out[f'{tag}.emb'], out[f'{tag}.y'] = npf(x), npf(emb), npf(y)
         out[f'{tag}.cfg'] = np.array([dim, k, int(mlp * 1000), h, w])
-    np.savez_compressed(os.path.join(HERE, 'cnx_block.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, 'cnx_block.npz'), **out)
     print('cnx_block.npz', len(out))
 
 
@@ -139,7 +140,7 @@ def golden_qarv(model, h, w, lmbs, tag, img_seed=0, full_features=True):
               [(int(r['symbols'].min()), int(r['symbols'].max())) for r in recs],
               'idx range', [(int(r['indexes'].min()), int(r['indexes'].max())) for r in recs],
               'dec-vs-sample', float(out[f'{key}.xhat_from_z_maxdiff']))
-    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'qarv_base_{tag}.npz'), **out)
 
 
 @torch.no_grad()
@@ -147,7 +148,7 @@ def golden_tables(model):
     """DiscretizedGaussian.update() tables as produced by the reference subclass (entropy_coding.py:52-82)
     on top of the CompressAI-semantics stand-in."""
     dg = model.dec_blocks[0].discrete_gaussian
-    np.savez_compressed(os.path.join(HERE, 'discretized_gaussian_tables.npz'),
+    np.savez_compressed(os.path.join(OUT, 'discretized_gaussian_tables.npz'),
                         scale_table=npf(dg.scale_table), quantized_cdf=npf(dg._quantized_cdf),
                         cdf_length=npf(dg._cdf_length), offset=npf(dg._offset))
     print('tables', tuple(dg._quantized_cdf.shape), int(dg._cdf_length.max()))
@@ -163,7 +164,7 @@ def golden_pack():
         out[f'case{i}.packed'] = np.frombuffer(packed, dtype=np.uint8)
         out[f'case{i}.lengths'] = np.array([len(s) for s in c])
         out[f'case{i}.joined'] = np.frombuffer(b''.join(c), dtype=np.uint8)
-    np.savez_compressed(os.path.join(HERE, 'pack_byte_strings.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, 'pack_byte_strings.npz'), **out)
 
 
 @torch.no_grad()
@@ -181,7 +182,7 @@ def golden_imcoding(model):
             r = imcoding_evaluate(model, d)
             res[f'lmb{int(lmb)}'] = r
         model.default_lmb = model.lmb_range[1]
-    with open(os.path.join(HERE, 'imcoding_evaluate.json'), 'w') as f:
+    with open(os.path.join(OUT, 'imcoding_evaluate.json'), 'w') as f:
         json.dump({'sizes': sizes, 'seeds': [100, 101, 102], 'results': res}, f, indent=1)
     print('imcoding', res)
 
@@ -206,7 +207,7 @@ def golden_progressive(model, h, w, lmb, tag, img_seed=0):
     out['x_uncond_t0'] = npf(x).astype(np.float32)
     print('progressive', tag, 'psnr vs input:',
           [round(float(-10 * np.log10(np.mean((out[f'x{a}'] - npf(im)) ** 2))), 2) for a in range(L)])
-    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}_progressive.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'qarv_base_{tag}_progressive.npz'), **out)
 
 
 @torch.no_grad()
@@ -238,7 +239,7 @@ def golden_robust(model, h, w, lmb, tag, img_seed=0):
     for name, lat in cases.items():
         x = model.conditional_sample(lmb=lmb, latents=lat, bhw_repeat=bhw, t=0)
         out[f'x.{name}'] = npf(x).astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, f'qarv_base_{tag}_robust.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'qarv_base_{tag}_robust.npz'), **out)
     print('robust', tag, sorted(cases))
 
 
@@ -264,7 +265,7 @@ def golden_qres(model, h, w, tag, img_seed=0, model_name='qres34m'):
                     return idx
 
                 def comp(qm, indexes, means=None):
-                    rec['pm'] = npf(means)
+                    rec['pm'], rec['qm'] = npf(means), npf(qm)
                     rec['symbols'] = npf(dg.quantize(qm, 'symbols', means)).astype(np.int32)
                     s = orig_c(qm, indexes, means=means)
                     rec['string'] = np.frombuffer(s[0], dtype=np.uint8)
@@ -285,7 +286,7 @@ def golden_qres(model, h, w, tag, img_seed=0, model_name='qres34m'):
     print(model_name, tag, 'payload bytes', sum(len(r['string']) for r in recs), 'pickle', int(out['pickle_bytes']),
           'sym range', [(int(r['symbols'].min()), int(r['symbols'].max())) for r in recs][:6],
           'idx range', [(int(r['indexes'].min()), int(r['indexes'].max())) for r in recs][:6])
-    np.savez_compressed(os.path.join(HERE, f'{model_name}_{tag}.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'{model_name}_{tag}.npz'), **out)
 
 
 @torch.no_grad()
@@ -312,7 +313,12 @@ def golden_qres_lossless(model, h, w, tag, img_seed=0):
         rec['string'] = np.frombuffer(s[0], dtype=np.uint8)
         return s
     dg.build_indexes, dg.compress = bi, comp
+    # the raw conv_mean / conv_scale outputs behind pm / scale (_preapre_codec, :69-79): what the guard-band check of a flipped
+    # per-pixel mean (round(m * 127.5 + 127.5)) or scale index needs
+    hm = on.conv_mean.register_forward_hook(lambda mod, a, o: rec.__setitem__('raw_mean', npf(o)))
+    hs = on.conv_scale.register_forward_hook(lambda mod, a, o: rec.__setitem__('raw_logscale', npf(o)))
     obj = model.compress(im)
+    hm.remove(); hs.remove()
     dg.build_indexes, dg.compress = orig_bi, orig_c
     for k, v in rec.items():
         out[f'out.{k}'] = v
@@ -328,7 +334,7 @@ def golden_qres_lossless(model, h, w, tag, img_seed=0):
     print('qres34m_lossless', tag, 'latent bytes', sum(len(s[0]) for s in obj[:-2]), 'pixel-stream bytes', len(obj[-1][0]),
           'bpp', 8 * (sum(len(s[0]) for s in obj[:-2]) + len(obj[-1][0])) / (h * w), 'lossless', bool(out['lossless']),
           'sym range', int(rec['symbols'].min()), int(rec['symbols'].max()), 'idx range', int(rec['indexes'].min()), int(rec['indexes'].max()))
-    np.savez_compressed(os.path.join(HERE, f'qres34m_lossless_{tag}.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'qres34m_lossless_{tag}.npz'), **out)
 
 
 def main_qres():
@@ -338,23 +344,36 @@ def main_qres():
     model.compress_mode()
     print('qres34m params', sum(p.numel() for p in model.parameters()) / 1e6, 'entries', len(model.state_dict()))
     dg = model.decoder.dec_blocks[0].discrete_gaussian
-    np.savez_compressed(os.path.join(HERE, 'gaussian_conditional_tables.npz'), scale_table=npf(dg.scale_table),
+    np.savez_compressed(os.path.join(OUT, 'gaussian_conditional_tables.npz'), scale_table=npf(dg.scale_table),
                         quantized_cdf=npf(dg._quantized_cdf), cdf_length=npf(dg._cdf_length), offset=npf(dg._offset))
     golden_qres(model, 64, 64, '64x64')
     golden_qres(model, 128, 192, '128x192', img_seed=1)
-    with open(os.path.join(HERE, 'qres34m_state_keys.json'), 'w') as f:
+    with open(os.path.join(OUT, 'qres34m_state_keys.json'), 'w') as f:
         json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'qres':
         return main_qres()
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        # the size BASELINE.json's metric is quoted on (configs 2 and 3): one 512x768 image per model, lambda = 2048 for qarv_base
+        # (qarv/model.py:516-557 at full size: symbols, indexes, pm / pv / qm of every block, the bitstream, x_hat)
+        model = lvae.get_model('qarv_base')
+        load_seeded(model, 0)
+        model.eval()
+        model.compress_mode()
+        golden_qarv(model, 512, 768, [2048.0], '512x768', img_seed=7, full_features=False)
+        model = lvae.get_model('qres34m')
+        load_seeded(model, 0)
+        model.eval()
+        model.compress_mode()
+        return golden_qres(model, 512, 768, '512x768', img_seed=7)
     if len(sys.argv) > 1 and sys.argv[1] == 'qres17m':
         model = lvae.get_model('qres17m')
         load_seeded(model, 0)
         model.eval()
         model.compress_mode()
-        with open(os.path.join(HERE, 'qres17m_state_keys.json'), 'w') as f:
+        with open(os.path.join(OUT, 'qres17m_state_keys.json'), 'w') as f:
             json.dump({k: list(v.shape) for k, v in model.state_dict().items() if 'discrete_gaussian' not in k}, f)
         return golden_qres(model, 64, 128, '64x128', model_name='qres17m')
     if len(sys.argv) > 1 and sys.argv[1] == 'lossless':
@@ -362,7 +381,7 @@ def main():
         load_seeded(model, 0)
         model.eval()
         model.compress_mode()
-        with open(os.path.join(HERE, 'qres34m_lossless_state_keys.json'), 'w') as f:
+        with open(os.path.join(OUT, 'qres34m_lossless_state_keys.json'), 'w') as f:
             json.dump({k: list(v.shape) for k, v in model.state_dict().items() if 'discrete_gaussian' not in k}, f)
         return golden_qres_lossless(model, 64, 128, '64x128')
     if len(sys.argv) > 1 and sys.argv[1] == 'progressive':

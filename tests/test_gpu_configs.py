@@ -200,6 +200,123 @@ def test_config2_qarv_base_b8_512x768_against_oracle():
     assert torch.equal(m.decompress_batch(strings)[5:6], m.decompress(strings[5]))
 
 
+def _golden_blocks(g, prefix, n_blocks):
+    """Per-block dicts (pm, pv, qm, indexes, symbols, z = symbols + pm) of a reference-generated golden (tests/golden/make_golden.py)."""
+    out = []
+    for bi in range(n_blocks):
+        b = {k: g[f'{prefix}b{bi}.{k}'] for k in ('pm', 'pv', 'qm', 'indexes', 'symbols')}
+        b['z'] = torch.from_numpy(b['symbols'].astype(np.float32) + b['pm'].astype(np.float32))
+        out.append(b)
+    return out
+
+
+def test_config2_qarv_base_512x768_against_reference_golden(golden_dir):
+    """The size BASELINE.json's metric is quoted on, held to a fixture the REFERENCE produced (tests/golden/make_golden.py full:
+    `lvae.get_model('qarv_base')` of /root/reference, lambda = 2048, image seed 7): qarv/model.py:516-557 at 512x768.
+    Image = batch row 3 of a batch of 8 (config 2 is a batch; the other rows are other images).  Teacher-forced guard-band proof for
+    all 617 472 elements, |dx| <= 1e-4 for the HIP decoder on the reference's latents AND for decoding the reference's own bitstream
+    when the free-running encoder has no flip on that image, byte-identical rANS strings block by block while symbols / indexes match."""
+    import parity_util
+    from conftest import load_seeded_into, parity_record
+    from oracle import qarv_oracle
+    from lvae.utils import coding
+    import lvae
+    g = np.load(os.path.join(golden_dir, 'qarv_base_512x768.npz'))
+    sd = seeded_init.seeded_state_dict(qarv_oracle.qarv_param_shapes(qarv_oracle.qarv_base_arch()), seed=0)
+    m = lvae.get_model('qarv_base')
+    load_seeded_into(m, sd)
+    m = m.to('cuda:0').eval()
+    m.compress_mode()
+    lmb, row, key = 2048.0, 3, 'lmb2048.'
+    mk = lambda s: torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, s)).permute(2, 0, 1).float().div(255)
+    ims = torch.stack([mk(int(g['img_seed'])) if i == row else mk(50 + i) for i in range(8)])
+    gb = _golden_blocks(g, key, 9)
+    case = 'qarv_base B=8 512x768 lmb=2048 row 3 vs REFERENCE GOLDEN'
+    trf = m.encode_trace(ims.cuda(), lmb, full=True, force_z=[([row], b['z']) for b in gb])
+    guard = parity_util.check_blocks(case, trf, gb, m._dg().scale_table.cpu().numpy(), m._packed.scale_bound, rows=[row])
+    x_ref = torch.from_numpy(g[key + 'xhat'])
+    err = float((m.conditional_sample(lmb, [b['z'].cuda() for b in gb]).cpu() - x_ref).abs().max())
+    # the reference's own container decodes here (same priors bit for bit unless an index sits on a threshold: then the stream is
+    # undecodable on ANY other arithmetic -- the reference's CPU vs CUDA included -- and only the latent-fed check above applies)
+    tr = m.encode_trace(ims.cuda(), lmb)
+    n = flips = iflips = n1 = f1 = 0
+    clean = True
+    strings = coding.unpack_byte_string(m.compress_batch(ims.cuda(), lmb)[row][10:])
+    same = True
+    for bi, (a, b) in enumerate(zip(tr, gb)):
+        sf = int((a['symbols'][row].reshape(-1) != b['symbols'].reshape(-1)).sum())
+        xf = int((a['indexes'][row].reshape(-1) != b['indexes'].reshape(-1)).sum())
+        n += b['symbols'].size; flips += sf; iflips += xf
+        if clean:
+            n1 += b['symbols'].size; f1 += sf + xf
+            if sf == 0 and xf == 0:
+                assert strings[bi] == g[f'{key}b{bi}.string'].tobytes(), f'{case}: block {bi} stream differs although symbols and indexes match'
+            clean = sf == 0
+        same = same and sf == 0 and xf == 0
+    if same:
+        err = max(err, float((m.decompress(g[key + 'bitstream'].tobytes()).cpu() - x_ref).abs().max()))
+    parity_record(f'{case} (free-running: first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, err, same, guard)
+    assert n == guard['n'] == 617472
+    assert err <= 1e-4, err
+    assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
+    assert f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
+
+
+def test_config3_qres34m_512x768_against_reference_golden(golden_dir):
+    """qres34m at 512x768 against the reference-generated fixture (qresvae/model.py:649-725 run by make_golden.py full): the same
+    three parts, plus the cross-decoder check -- the HIP encoder's strings decoded by the ORACLE's decoder (the container and the
+    bitstream against the reference's semantics) give its reconstruction to 1e-4 when the free-running encode has no flip, and the
+    total free-running flip count stays sane."""
+    import parity_util
+    from conftest import parity_record
+    from oracle import qres_oracle
+    import lvae
+    g = np.load(os.path.join(golden_dir, 'qres34m_512x768.npz'))
+    sd = seeded_init.seeded_state_dict(qres_oracle.qres_param_shapes(qres_oracle.qres34m_arch()), seed=0)
+    m = lvae.get_model('qres34m')
+    full = m.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    m.load_state_dict(full)
+    m.compress_mode()
+    m = m.to('cuda:0').eval()
+    im = torch.from_numpy(seeded_init.synthetic_image_u8(512, 768, int(g['img_seed']))).permute(2, 0, 1).float().div(255).unsqueeze(0)
+    gb = _golden_blocks(g, '', 12)
+    zs = [b['z'] for b in gb]
+    case = 'qres34m 512x768 vs REFERENCE GOLDEN'
+    guard = parity_util.check_blocks(case, m.encode_trace(im.cuda(), full=True, force_z=zs), gb,
+                                     m._dg().scale_table.cpu().numpy(), m._packed.scale_bound)
+    x_ref = torch.from_numpy(g['xhat'])
+    err = float((m.cond_sample([z.cuda() for z in zs]).cpu() - x_ref).abs().max())
+    tr = m.encode_trace(im.cuda())
+    obj = m.compress(im.cuda())
+    n = flips = iflips = n1 = f1 = 0
+    clean = True
+    for bi, (a, b) in enumerate(zip(tr, gb)):
+        sf = int((a['symbols'].reshape(-1) != b['symbols'].reshape(-1)).sum())
+        xf = int((a['indexes'].reshape(-1) != b['indexes'].reshape(-1)).sum())
+        n += b['symbols'].size; flips += sf; iflips += xf
+        if clean:
+            n1 += b['symbols'].size; f1 += sf + xf
+            if sf == 0 and xf == 0:
+                assert obj[bi][0] == g[f'b{bi}.string'].tobytes(), f'{case}: block {bi} stream differs although symbols and indexes match'
+            clean = sf == 0
+    parity_record(f'{case} (free-running: first-order flips {f1} in the {n1} symbols up to the first symbol flip, totals incl. its cascade:)',
+                  flips, iflips, n, err, flips + iflips == 0, guard)
+    assert n == guard['n'] == 841728 and tuple(obj[-1]) == tuple(g['smallest'].tolist())
+    assert err <= 1e-4, err
+    assert guard['sym_flips'] + guard['idx_flips'] <= 1e-4 * n, guard
+    assert f1 <= 1e-4 * n1, (f1, n1, flips, iflips, n)
+    assert flips + iflips <= 0.05 * n, (flips, iflips, n)              # loose sanity bound on the cascade (ADVICE r03)
+    # cross-decoder: the oracle decodes the HIP strings (its priors differ from the HIP decoder's by rounding noise only)
+    orc = qres_oracle.QresOracle(sd)
+    orc.compress_mode()
+    if flips + iflips == 0:
+        assert float((orc.decompress(obj) - x_ref).abs().max()) <= 1e-4
+    assert torch.equal(m.decompress(obj), m.decompress(m.compress(im.cuda())))
+
+
 # ------------------------------------------------------------------------------------------------------------------ config 4
 def _sharded_worker(rank, world, dataset, ckpt, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -316,7 +316,7 @@ def test_prior_index_quantize_dequantize(L):
     prm = (torch.randn(M, 2 * z, generator=g) * 2).cuda()
     table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).cuda()
     pm, idx = torch.empty(M, z, device='cuda'), torch.empty(B, z, HW, dtype=torch.uint8, device='cuda')
-    assert L.lvae_prior_index_f32(prm.data_ptr(), pm.data_ptr(), idx.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, _st()) == 0
+    assert L.lvae_prior_index_f32(prm.data_ptr(), pm.data_ptr(), idx.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, None, _st()) == 0
     torch.cuda.synchronize()
     assert torch.equal(pm, prm[:, :z])
     pv64 = torch.exp(F.softplus(prm[:, z:].double() + 2.3) - 2.3)
@@ -328,7 +328,7 @@ def test_prior_index_quantize_dequantize(L):
     # quantize / dequantize
     qm = (torch.randn(M, z, generator=g) * 6).cuda()
     sym, zhat = torch.empty(B, z, HW, dtype=torch.int32, device='cuda'), torch.empty(M, z, device='cuda')
-    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, z, _st()) == 0
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, z, None, _st()) == 0
     torch.cuda.synchronize()
     r = torch.round(qm - pm)
     assert torch.equal(sym, r.int().view(B, HW, z).permute(0, 2, 1).contiguous())
@@ -341,7 +341,7 @@ def test_prior_index_quantize_dequantize(L):
     qh = torch.tensor([[0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, 4.5]], device='cuda')
     ph = torch.zeros_like(qh)
     sh, zh = torch.empty(1, 8, 1, dtype=torch.int32, device='cuda'), torch.empty(1, 8, device='cuda')
-    assert L.lvae_quantize_f32(qh.data_ptr(), ph.data_ptr(), sh.data_ptr(), zh.data_ptr(), 1, 1, 8, 8, _st()) == 0
+    assert L.lvae_quantize_f32(qh.data_ptr(), ph.data_ptr(), sh.data_ptr(), zh.data_ptr(), 1, 1, 8, 8, None, _st()) == 0
     torch.cuda.synchronize()
     assert sh.flatten().tolist() == [0, 2, 2, 0, -2, -2, 4, 4]
 
@@ -374,7 +374,7 @@ def test_quantize_padded_rows_and_gemm_a_gelu(L):
     qm, pm = (torch.randn(M, z, generator=g) * 5).cuda(), torch.randn(M, z, generator=g).cuda()
     sym = torch.empty(B, z, HW, dtype=torch.int32, device='cuda')
     zhat = torch.full((M, ldz), float('nan'), device='cuda')
-    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, ldz, _st()) == 0
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, ldz, None, _st()) == 0
     torch.cuda.synchronize()
     r = torch.round(qm - pm)
     assert torch.equal(zhat[:, :z], r + pm) and torch.equal(zhat[:, z:], torch.zeros(M, 2, device='cuda'))

@@ -81,8 +81,11 @@ def test_cnx_block(golden_dir):
         np.testing.assert_allclose(y.numpy(), g[f'{tag}.y'], rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
+@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1), ('512x768', 7)])      # 512x768: the size the metric is quoted on
 def test_full_model(golden_dir, oracle_model, tag, seed):
+    if tag == '512x768' and not EXACT:
+        pytest.skip('free-running full-size comparison: exact on the host that generated the golden; elsewhere one rounding flip cascades '
+                    '(the -m gpu tests hold the HIP path to this golden teacher-forced)')
     g = np.load(os.path.join(golden_dir, f'qarv_base_{tag}.npz'))
     h, w = g['hw'].tolist()
     im = _img(h, w, seed)

@@ -55,8 +55,11 @@ def test_product_state_dict_and_tables(golden_dir):
     m.load_state_dict(sd)
 
 
-@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1)])
+@pytest.mark.parametrize('tag,seed', [('64x64', 0), ('128x192', 1), ('512x768', 7)])      # 512x768: BASELINE config 3's size
 def test_oracle_matches_reference(golden_dir, oracle, tag, seed):
+    if tag == '512x768' and not EXACT:
+        pytest.skip('free-running full-size comparison: exact on the host that generated the golden; elsewhere one rounding flip cascades '
+                    '(the -m gpu tests hold the HIP path to this golden teacher-forced)')
     g = np.load(os.path.join(golden_dir, f'qres34m_{tag}.npz'))
     h, w = g['hw'].tolist()
     im = _img(h, w, seed)
@@ -105,7 +108,18 @@ def _hip_golden_case(product, g, im, case, n_blocks=12):
             assert fixed == gold, f'{case}: block {bi}'
     xhat = product.decompress(obj)
     err = float((xhat.cpu() - torch.from_numpy(g['xhat'])).abs().max())
-    parity_record(case, flips, iflips, n, err, same)
+    # every flip must be a guard-band event and every element within rounding noise of the reference (tests/parity_util.py):
+    # teacher-forced with the reference's latents, so a flip is never the cascade of an earlier one
+    import parity_util
+    gb = []
+    for bi in range(n_blocks):
+        b = {k: g[f'b{bi}.{k}'] for k in ('pm', 'pv', 'qm', 'indexes', 'symbols')}
+        b['z'] = torch.from_numpy(b['symbols'].astype(np.float32) + b['pm'].astype(np.float32))
+        gb.append(b)
+    guard = parity_util.check_blocks(case, product.encode_trace(im, full=True, force_z=[b['z'] for b in gb]), gb,
+                                     product._dg().scale_table.cpu().numpy(), product._packed.scale_bound)
+    assert guard['n'] == n
+    parity_record(case, flips, iflips, n, err, same, guard)
     assert np.array_equal(tr[0]['symbols'].reshape(-1), g['b0.symbols'].reshape(-1))
     assert flips <= MAX_SYM_FLIPS and iflips <= MAX_IDX_FLIPS, (case, flips, iflips, n)
     assert err <= 1e-4, (case, err)
@@ -205,6 +219,43 @@ def lossless_product(lossless_sd):
     return m.to('cuda:0').eval()
 
 
+def _lossless_pixel_guard(pl, g, sym, idx, h, w):
+    """Guard-band proof for the per-pixel stream of GaussianNLLOutputNet (qresvae/model.py:69-94) against the reference golden.  With the
+    12 latent strings byte-identical the output net sees the reference's feature up to rounding noise, so: every raw mean / log-scale
+    (the conv_mean | conv_scale outputs, `out.raw_*` of the golden) within VAL_ATOL / LNS_TOL for ALL 3*H*W elements; a flipped SYMBOL
+    is a flipped rounded mean -- pm = round(m * 127.5 + 127.5) differs by one because m * 127.5 + 127.5 sits on a half-integer (margin
+    <= 127.5 * VAL_ATOL on both sides), the image sample being the same integer on both sides; a flipped INDEX has its scale
+    exp(ls) / bin within IDX_BAND of the table threshold between the two rows on both sides.  -> the dict check_blocks returns."""
+    import parity_util as pu
+    raw = pl.px_raw.cpu().numpy().reshape(1, h, w, 6).astype(np.float64)                  # NHWC: mean c0..2 | log-scale c0..2
+    m_hip, ls_hip = raw[..., :3].transpose(0, 3, 1, 2), raw[..., 3:].transpose(0, 3, 1, 2)
+    m_ref, ls_ref = g['out.raw_mean'].astype(np.float64), g['out.raw_logscale'].astype(np.float64)
+    st = dict(sym_flips=0, idx_flips=0, n=sym.size, max_dval=float(np.abs(m_hip - m_ref).max()), max_dlns=float(np.abs(ls_hip - ls_ref).max()),
+              worst_sym_margin=0.0, worst_idx_margin=0.0)
+    assert st['max_dval'] <= pu.VAL_ATOL and st['max_dlns'] <= pu.LNS_TOL, st
+    table = g['scale_table'].astype(np.float64)
+    lnbin = -4.848116360536466                                                            # math.log(1 / 127.5)
+    for pos in zip(*np.nonzero(idx != g['out.indexes'])):
+        ia, ib = int(idx[pos]), int(g['out.indexes'][pos])
+        assert abs(ia - ib) == 1, (pos, ia, ib)
+        thr = table[min(ia, ib)]
+        mg = max(abs(max(np.exp(ls_hip[pos] - lnbin), 0.11) / thr - 1), abs(max(np.exp(ls_ref[pos] - lnbin), 0.11) / thr - 1))
+        st['idx_flips'] += 1
+        st['worst_idx_margin'] = max(st['worst_idx_margin'], float(mg))
+        assert mg <= pu.IDX_BAND, (pos, mg)
+    for pos in zip(*np.nonzero(sym != g['out.symbols'])):
+        sa, sb = int(sym[pos]), int(g['out.symbols'][pos])
+        assert abs(sa - sb) == 1, (pos, sa, sb)
+        va, vb = m_hip[pos] * 127.5 + 127.5, m_ref[pos] * 127.5 + 127.5                      # the value torch.round sees (:72)
+        assert abs(np.rint(va) - np.rint(vb)) == 1, (pos, va, vb)                             # the two rounded means are neighbours
+        half = (np.rint(va) + np.rint(vb)) / 2.0
+        mg = max(abs(va - half), abs(vb - half))
+        st['sym_flips'] += 1
+        st['worst_sym_margin'] = max(st['worst_sym_margin'], float(mg))
+        assert mg <= 127.5 * pu.VAL_ATOL, (pos, va, vb, mg)
+    return st
+
+
 @pytest.mark.gpu
 def test_lossless_hip_matches_reference_and_is_lossless(golden_dir, lossless_product, tmp_path):
     from PIL import Image
@@ -221,9 +272,10 @@ def test_lossless_hip_matches_reference_and_is_lossless(golden_dir, lossless_pro
     n = sym.size
     flips = int((sym != g['out.symbols']).sum()) + int((idx != g['out.indexes']).sum())
     print(f'qres34m_lossless: latent strings identical: {lat_same}; pixel stream flips {flips} of {n}; max|dpm| {np.abs(pm - g["out.pm"]).max()}')
+    guard = _lossless_pixel_guard(pl, g, sym, idx, h, w)
     from conftest import parity_record
     parity_record('qres34m_lossless 64x128 (12 latent streams + per-pixel stream)', int((sym != g['out.symbols']).sum()),
-                  int((idx != g['out.indexes']).sum()), n, 0.0, lat_same and flips == 0)
+                  int((idx != g['out.indexes']).sum()), n, 0.0, lat_same and flips == 0, guard)
     # absolute ceilings (MI355X today: latent strings byte-identical, 2 of 24 576 per-pixel elements off by one table row / unit)
     assert lat_same and flips <= 4, (lat_same, flips, n)
     if lat_same and flips == 0:

@@ -172,6 +172,43 @@ def gemms4():
         print(f'M={M:7d} N={N:5d} K={K:5d} epi={epi}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.2f} TF/s  {by / t / 1e12:5.2f} TB/s')
 
 
+def mlppanel():
+    """Does the hidden map of an MLP have to travel through HBM?  fc1 -> fc2 of a ConvNeXt block as two pre-split GEMM launches over the
+    whole map, against the same launches over P row panels with ONE panel-sized hidden buffer that is written and re-read while it is
+    still in the 256 MiB Infinity Cache (rows are independent: same bits).  Working set around it as in the model: y, res, out full size."""
+    from lvae.models.base import pack_f16x2_k32
+    for (C, HID, M) in [(192, 384, 196608), (192, 384, 98304), (384, 768, 49152), (384, 768, 24576), (256, 448, 49152), (128, 192, 196608)]:
+        yf = torch.randn(M, C, device='cuda')
+        W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
+        b1, b2, gamma = torch.randn(HID, device='cuda'), torch.randn(C, device='cuda'), torch.rand(C, device='cuda')
+        res, out = torch.randn(M, C, device='cuda'), torch.empty(M, C, device='cuda')
+        y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+        flush = torch.empty(96 * 1024 * 1024, device='cuda')             # 384 MB written between repetitions: nothing of the last run is cached
+        row = []
+        for P in (1, 2, 4, 8, 16):
+            mp = M // P
+            hid = torch.empty(mp, HID, device='cuda')
+            descs = []
+            for i in range(P):
+                d1, d2 = GemmDesc(), GemmDesc()
+                d1.A0, d1.lda0, d1.K0, d1.Wt, d1.Wt16, d1.ldw, d1.bias, d1.out, d1.ldo = y.data_ptr() + i * mp * C * 4, C, C, W1.data_ptr(), w1h.data_ptr(), C, b1.data_ptr(), hid.data_ptr(), HID
+                d1.M, d1.N, d1.K, d1.epi, d1.prec, d1.a_h2, d1.out_h2 = mp, HID, C, 1, 4, 1, 1
+                d2.A0, d2.lda0, d2.K0, d2.Wt, d2.Wt16, d2.ldw, d2.bias, d2.gamma = hid.data_ptr(), HID, HID, W2.data_ptr(), w2h.data_ptr(), HID, b2.data_ptr(), gamma.data_ptr()
+                d2.res, d2.ldres, d2.out, d2.ldo = res.data_ptr() + i * mp * C * 4, C, out.data_ptr() + i * mp * C * 4, C
+                d2.M, d2.N, d2.K, d2.epi, d2.prec, d2.a_h2 = mp, C, HID, 2, 4, 1
+                descs.append((d1, d2))
+
+            def run():
+                flush.fill_(1.0)
+                for d1, d2 in descs:
+                    L.lvae_gemm_f32(ctypes.byref(d1), st()); L.lvae_gemm_f32(ctypes.byref(d2), st())
+            t_all = timeit(run, iters=10)
+            t_flush = timeit(lambda: flush.fill_(1.0), iters=10)
+            row.append((P, (t_all - t_flush) * 1e6))
+        base = row[0][1]
+        print(f'C={C} hid={HID} M={M}: ' + '  '.join(f'P={p}: {t:7.1f} us ({base / t:4.2f}x)' for p, t in row) + f'   [{4.0 * M * C * HID / (min(t for _, t in row) * 1e-6) / 1e12:.0f} TF/s best]')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gemmx':
         gemmx()
@@ -179,6 +216,8 @@ if __name__ == '__main__':
         gemms4()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mlpf':
         mlpf()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mlppanel':
+        mlppanel()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk':
         for b in (1, 2, 4, 8, 16):
             gemmsk(b)
