@@ -1,0 +1,362 @@
+// mlp_h2c.hip -- the MLP of a ConvNeXt block as ONE persistent kernel for block shapes whose weights do NOT fit a CU's LDS
+// (f16x2 arithmetic, pre-split operands):      out = x + gamma * ( fc2( gelu( fc1(y) + b1 ) ) + b2 )      (lvae/models/common.py:131-132,154-158)
+// -- first of all the encoder's seven stride-4 blocks, C = 192 / hidden = 384 (qarv/zoo.py:38-40).  As two launches (gemm_h2p.hip) such a
+// block writes and re-reads its hidden map through HBM (302 MB each way at batch 8: the two launches run at 2.3 / 3.4 TB/s and
+// 146 / 164 TFLOP/s, profiles/r03_op_times_*), and every tile's GELU / split / store epilogue is serial with its short main loop
+// (K = 192: six 32-deep stages).  Here a workgroup (8 waves, 128 rows) walks the hidden dimension in chunks of 128 and keeps the
+// chunk on the CU:
+//   per chunk:  P[128 x 128] = y W1_c^T over K = C        (C/32 "F" stages: A rows + the chunk's W1 rows, 32 KB per stage)
+//               H = split(gelu(P + b1_c)) -> LDS           (64 KB, stage layout of an A operand)
+//               O[128 x C] += H W2_c^T over K = 128        (4 "G" stages: the chunk's W2 columns, C x 128 B per stage)
+//   per tile:   out = res + gamma * (O + b2)
+// All global -> LDS traffic is LDS-DMA (`buffer_load ... lds`, whole 128-B lines, source-side swizzle: gemm_h2p.hip) through ONE ring of
+// three 32 KB slots that runs flat across F stages, G stages, chunks and TILES (the workgroup is persistent: the next tile's first two
+// stages are in flight while this tile's epilogue stores drain), two stages ahead, one raw s_barrier + counted vmcnt per stage.
+// Every (tile-relative) stage position is compile-time -- the whole tile is unrolled -- so ring slots, LDS offsets and the vmcnt
+// allowances are immediates.  LDS: 3 x 32 KB ring + 64 KB hidden chunk = the CU's 160 KB.
+// Arithmetic per element is the two-launch path's, operation for operation (mlp_h2f.hip says how): per accumulator the MFMA sequence of
+// gemm_h2p_kernel (k16 steps ascending -- chunks and G stages ascend in the hidden index), fma(accX, 2^-11, accH), the same epilogue
+// roundings, the same split -- so every output bit equals fc2(fc1(.)) through gemm_h2p (tests/test_gpu_f16x2.py::
+// test_mlp_h2c_equals_two_gemms) and the host may use it for this block shape at every batch size.
+#include "gemm_common.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define H2C_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <int C_, int HID_>
+struct H2C {
+    static constexpr int C = C_, HID = HID_, BM = 128, HC = 128;
+    static constexpr int NCH = HID / HC;                 // hidden chunks per tile
+    static constexpr int KS1 = C / 32, KS2 = HC / 32;    // F / G stages per chunk
+    static constexpr int PT = KS1 + KS2;                 // stage positions per chunk
+    static constexpr int NP = NCH * PT;                  // ... per tile
+    static constexpr int NB2 = C / 64;                   // output column blocks of a wave (wave tile 32 x C/2)
+    static constexpr int SLOT = 32 * 1024, NBUF = 3, RING = NBUF * SLOT;
+    static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: 4 stages of 128 rows x 128 B
+    static constexpr int LDS = RING + HBYTES;
+    static constexpr int NI_F = (BM + HC) / 64;          // DMA instructions per wave: F stage (A rows + W1 rows; 8 rows each, 8 waves)
+    static constexpr int NI_G = C / 64;                  // ... G stage (C rows of W2)
+    static_assert(HID % HC == 0 && C % 64 == 0 && NP % NBUF == 0, "shape");
+    static_assert(C * 128 <= SLOT && LDS <= 160 * 1024, "LDS");
+    static constexpr bool is_f(int p) { return (p % PT) < KS1; }
+    static constexpr int ni(int p) { return is_f(p % NP) ? NI_F : NI_G; }
+};
+
+template <int C_, int HID_>          // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
+__global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, int n_tiles) {
+    // (device pass only: hipcc's HOST pass cannot instantiate the generic lambdas below -- the kernel template then silently drops out
+    //  of overload resolution and no launch stub is emitted; the host needs nothing but the stub)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(off)
+    using S = H2C<C_, HID_>;
+    constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((char*)smem);
+
+    // per-column parameters of this lane's output columns (requested before the DMA queue fills: loads retire in order)
+    float b2v[NB2], gmv[NB2], b1v[S::NCH][2];
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) { b2v[b] = d.b2[wn * (C / 2) + 32 * b + li]; gmv[b] = d.gamma[wn * (C / 2) + 32 * b + li]; }
+#pragma unroll
+    for (int ch = 0; ch < S::NCH; ++ch)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) b1v[ch][b] = d.b1[ch * S::HC + 64 * wn + 32 * b + li];       // fc1 bias of this lane's hidden columns, every chunk
+
+    // ---- DMA side: instruction g of an operand block covers its rows 8g .. 8g + 7 (one 128-B line each); wave w issues g = i * 8 + w,
+    // so g has the parity of w and the source permutation ((row >> 1) & 7 = (4 (w & 1) + (r_in >> 1)) & 7) is a per-lane constant
+    const int r_in = lane >> 3, pp = lane & 7;
+    const int perm = (pp ^ ((4 * (wave & 1) + (r_in >> 1)) & 7)) << 4;
+    const int dvA = r_in * (C * 4) + perm;               // A / W1 rows are C * 4 bytes (H2K32)
+    const int dvW2 = r_in * (HID * 4) + perm;            // W2 rows are HID * 4 bytes
+    const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w1, 0, HID * C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w2, 0, C * HID * 4, 0x00020000);
+    // issue the DMA instructions of tile-relative position P (compile time) of the tile whose A rows start at `abase` (`arows` valid rows;
+    // 0 rows = nothing to fetch: every lane out of range, the slot is zero-filled -- keeps the instruction count, hence vmcnt, uniform)
+    auto dma_pos = [&](auto ptag, int i, const char* abase, int arows) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value % NP, CH = P / PT, Q = P % PT, SL = P % S::NBUF;
+        char* slot = (char*)smem + SL * S::SLOT;
+        // (opaque copy: without it hipcc hoists the scalar offsets of all NP x NI instructions out of the tile loop and spills them)
+        int wv = wave;
+        asm volatile("" : "+s"(wv));
+        const int g = i * 8 + wv;
+        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. 127 | W1 rows CH * 128 .. + 127, k32 index Q
+            if (i < 2) {
+                const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, arows * (C * 4), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA, 8 * g * (C * 4) + Q * 128, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA,
+                                                         (CH * S::HC + 8 * (g - 16)) * (C * 4) + Q * 128, 0, 0);
+            }
+        } else {                                         // G stage: W2 rows 0 .. C - 1, k32 index CH * 4 + (Q - KS1) of the hidden dimension
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvW2,
+                                                     8 * g * (HID * 4) + (CH * KS2 + (Q - KS1)) * 128, 0, 0);
+        }
+    };
+
+    // fragment addresses: piece (plane p, k16 step t, lane half) = 4p + 2t + lh at ((piece ^ x) << 4) of the lane's row; the hidden
+    // chunk uses rot3 of the row permutation (mlp_h2f.hip: separates rows m and m + 2 in the ds_write_b64 pattern of the GELU phase)
+    const int xr = (li >> 1) & 7, xh = ((xr << 1) & 7) | (xr >> 2);
+    unsigned po[4], ph[4];                               // [2p + t]
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        po[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xr) << 4);
+        ph[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xh) << 4);
+    }
+    const unsigned a_row = lds0 + (32 * wm + li) * 128;                       // + slot: A rows of an F stage
+    const unsigned w1_row = lds0 + BM * 128 + (64 * wn + li) * 128;           // + slot: W1 rows of an F stage
+    const unsigned w2_row = lds0 + (wn * (C / 2) + li) * 128;                 // + slot: W2 rows of a G stage
+    const unsigned h_row = lds0 + S::RING + (32 * wm + li) * 128;             // + g * 16 KB: hidden rows
+
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const char* ybase = (const char*)d.y;
+    auto tile_abase = [&](int t) { return ybase + (long)t * BM * (C * 4); };
+    auto tile_rows = [&](int t) { const int r = d.M - t * BM; return t < n_tiles ? (r < BM ? r : BM) : 0; };
+
+    // prologue: positions 0 and 1 of the first tile
+    {
+        const char* ab = tile_abase(tile);
+        const int ar = tile_rows(tile);
+        static_for<S::NI_F>([&](auto i) { dma_pos(std::integral_constant<int, 0>{}, decltype(i)::value, ab, ar); });
+        static_for<S::NI_F>([&](auto i) { dma_pos(std::integral_constant<int, 1>{}, decltype(i)::value, ab, ar); });
+    }
+
+    f32x16 oH[NB2], oX[NB2], pH[2], pX[2];
+    bool first = true;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        const int nxt = tile + gridDim.x;
+        const char* ab_cur = tile_abase(tile);
+        const int ar_cur = tile_rows(tile);
+        const char* ab_nxt = tile_abase(nxt < n_tiles ? nxt : tile);
+        const int ar_nxt = tile_rows(nxt);
+#pragma unroll
+        for (int b = 0; b < NB2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oH[b][r] = 0.f; oX[b][r] = 0.f; }
+
+        static_for<NP>([&](auto ptag) {
+            constexpr int P = decltype(ptag)::value, CH = P / PT, Q = P % PT, SL = P % S::NBUF;
+            constexpr bool F = Q < KS1;
+            constexpr int P2 = P + 2;                                        // the position whose DMAs are issued during this stage
+            constexpr int NI2 = S::ni(P2);
+            const char* ab2 = P2 >= NP ? ab_nxt : ab_cur;
+            const int ar2 = P2 >= NP ? ar_nxt : ar_cur;
+            if constexpr (Q == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { pH[b][r] = 0.f; pX[b][r] = 0.f; }
+            }
+            // ---- my DMA instructions of this position have landed once only those of position P + 1 are outstanding; after the barrier
+            // everyone's have, and everyone is done with position P - 1.
+            // Positions 0 and 1 of a tile that follows another one were waited for before that tile's epilogue stores (below).
+            if (P >= 2 || first) {
+                constexpr int ALLOW = S::ni(P + 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");
+            LVAE_FENCE();
+            int issued = 0;
+            if constexpr (F) {
+                // ---- fc1 stage: P[32 x 64] += A[32 x 32k] W1[64 x 32k]^T
+                f16x8 af[2][2], wf[2][2][2];                                  // [t][plane], [t][b][plane]
+                // (opaque: the per-slot, per-piece addresses are recomputed per stage -- four v_add in MFMA shadows -- instead of being
+                //  hoisted out of the tile loop as ~30 loop-invariant registers, which hipcc then spills)
+                unsigned aq = a_row + SL * S::SLOT, wq = w1_row + SL * S::SLOT;
+                asm volatile("" : "+v"(aq), "+v"(wq));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    H2C_DSR(af[t][0], aq + po[0 + t], 0);
+                    H2C_DSR(af[t][1], aq + po[2 + t], 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        H2C_DSR(wf[t][b][0], wq + po[0 + t], b * 4096);
+                        H2C_DSR(wf[t][b][1], wq + po[2 + t], b * 4096);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (t == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]));
+                    LVAE_FENCE();
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            if (j == 0) pX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][1], wf[t][b][0], pX[b], 0, 0, 0);
+                            else if (j == 1) pX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][1], pX[b], 0, 0, 0);
+                            else pH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][0], pH[b], 0, 0, 0);
+                        }
+                        if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                        LVAE_FENCE();
+                    }
+                }
+                static_assert(S::NI_F <= 6 && S::NI_G <= 6, "DMA instructions per stage must fit behind the MFMA groups of a stage");
+                if constexpr (Q == KS1 - 1) {
+                    // ---- GELU phase: hidden chunk = split(gelu(P + b1)) -> LDS in the stage layout of an A operand (row m of stage
+                    // c / 32: 64 B hi | 64 B lo', 16-B pieces permuted).  After the quad transpose a lane holds 4 consecutive columns of a row.
+                    // (opaque lane coordinates: the 16 store addresses of this phase are recomputed here instead of living -- spilled --
+                    //  across the whole tile loop)
+                    int lio = li, lho = lh;
+                    asm volatile("" : "+v"(lio), "+v"(lho));
+                    const int lj = lio & 3;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int cs = 2 * wn + b;                            // hidden columns 64 wn + 32 b .. + 31 of the chunk = stage cs
+                        const int cc = lio & ~3;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v0 = __builtin_fmaf(pX[b][4 * g + 0], 1.0f / 2048.0f, pH[b][4 * g + 0]) + b1v[CH][b];
+                            float v1 = __builtin_fmaf(pX[b][4 * g + 1], 1.0f / 2048.0f, pH[b][4 * g + 1]) + b1v[CH][b];
+                            float v2 = __builtin_fmaf(pX[b][4 * g + 2], 1.0f / 2048.0f, pH[b][4 * g + 2]) + b1v[CH][b];
+                            float v3 = __builtin_fmaf(pX[b][4 * g + 3], 1.0f / 2048.0f, pH[b][4 * g + 3]) + b1v[CH][b];
+                            gelu_erf2(v0, v1); gelu_erf2(v2, v3);
+                            quad_transpose(v0, v1, v2, v3, lj);
+                            unsigned h0, l0, h1, l1;
+                            split_pair_h2(v0, v1, h0, l0);
+                            split_pair_h2(v2, v3, h1, l1);
+                            const int m = 32 * wm + 4 * lho + 8 * g + lj;
+                            const int k = (m >> 1) & 7, x = ((k << 1) & 7) | (k >> 2);
+                            const unsigned base = lds0 + S::RING + cs * (BM * 128) + m * 128 + ((cc & 7) << 1);
+                            const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 0) ^ x) << 4)), "v"(hi2) : "memory");
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 4) ^ x) << 4)), "v"(lo2) : "memory");
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the hidden chunk is in LDS before the next barrier
+                }
+            } else {
+                // ---- fc2 stage: O[32 x C/2] += H[32 x 32k] W2[C/2 x 32k]^T
+                constexpr int G = Q - KS1;
+                f16x8 af[2][2], wf[2][NB2][2];
+                unsigned aq = h_row + G * (BM * 128), wq = w2_row + SL * S::SLOT;
+                asm volatile("" : "+v"(aq), "+v"(wq));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    H2C_DSR(af[t][0], aq + ph[0 + t], 0);
+                    H2C_DSR(af[t][1], aq + ph[2 + t], 0);
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b) {
+                        H2C_DSR(wf[t][b][0], wq + po[0 + t], b * 4096);
+                        H2C_DSR(wf[t][b][1], wq + po[2 + t], b * 4096);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (t == 0) {
+                        if constexpr (NB2 == 3) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]), "+v"(wf[0][2][0]), "+v"(wf[0][2][1]));
+                        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]));
+                    } else {
+                        if constexpr (NB2 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]), "+v"(wf[1][2][0]), "+v"(wf[1][2][1]));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]));
+                    }
+                    LVAE_FENCE();
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                        for (int b = 0; b < NB2; ++b) {
+                            if (j == 0) oX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][1], wf[t][b][0], oX[b], 0, 0, 0);
+                            else if (j == 1) oX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][1], oX[b], 0, 0, 0);
+                            else oH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][0], oH[b], 0, 0, 0);
+                        }
+                        if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                        LVAE_FENCE();
+                    }
+                }
+            }
+        });
+        first = false;
+
+        // ---- epilogue 2: out = res + gamma * (O + b2)   (gemm_epilogue's order: + bias, * gamma, transpose, + residual).  The residual
+        // rows are requested first; then the next tile's first two stages (in flight since the last two G stages) are waited for HERE,
+        // before the stores: a counted vmcnt behind a store burst would make the next stages wait for the stores to drain.
+        {
+            int lio = li, lho = lh;
+            asm volatile("" : "+v"(lio), "+v"(lho));
+            const int lj = lio & 3;
+            // every residual row is requested before anything is stored (the P accumulators are dead: their registers hold the 4 * NB2
+            // residual vectors): with stores in flight hipcc waits for a load with vmcnt(0), i.e. for the stores to drain
+            f32x4 rv[4][NB2];
+            int rb[4];
+            bool rok[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = m0 + 32 * wm + 4 * lho + 8 * g + lj;
+                rok[g] = row < d.M;
+                rb[g] = (rok[g] ? row : 0) * C;                             // (M * C < 2^31: checked on the host)
+#pragma unroll
+                for (int b = 0; b < NB2; ++b) rv[g][b] = *(const f32x4*)(d.res + rb[g] + wn * (C / 2) + 32 * b + (lio & ~3));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int b = 0; b < NB2; ++b) {
+                    float v0 = (__builtin_fmaf(oX[b][4 * g + 0], 1.0f / 2048.0f, oH[b][4 * g + 0]) + b2v[b]) * gmv[b];
+                    float v1 = (__builtin_fmaf(oX[b][4 * g + 1], 1.0f / 2048.0f, oH[b][4 * g + 1]) + b2v[b]) * gmv[b];
+                    float v2 = (__builtin_fmaf(oX[b][4 * g + 2], 1.0f / 2048.0f, oH[b][4 * g + 2]) + b2v[b]) * gmv[b];
+                    float v3 = (__builtin_fmaf(oX[b][4 * g + 3], 1.0f / 2048.0f, oH[b][4 * g + 3]) + b2v[b]) * gmv[b];
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    oH[b][4 * g + 0] = v0; oH[b][4 * g + 1] = v1; oH[b][4 * g + 2] = v2; oH[b][4 * g + 3] = v3;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // residual rows here; next tile's positions 0 and 1 landed
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int b = 0; b < NB2; ++b) {
+                    if (rok[g]) {
+                        f32x4 o = {oH[b][4 * g + 0], oH[b][4 * g + 1], oH[b][4 * g + 2], oH[b][4 * g + 3]};
+                        o[0] += rv[g][b][0]; o[1] += rv[g][b][1]; o[2] += rv[g][b][2]; o[3] += rv[g][b][3];
+                        *(f32x4*)(d.out + rb[g] + wn * (C / 2) + 32 * b + (lio & ~3)) = o;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <int C_, int HID_>
+int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
+    using S = H2C<C_, HID_>;
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_>, S::LDS)) return ae;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if ((long)d->M * S::C * 4 > 0x7fffffffL) return -22;    // 32-bit row offsets in the epilogue, one buffer descriptor per tile base
+    const int n_tiles = (d->M + S::BM - 1) / S::BM;
+    const int grid = n_tiles < n_cu ? n_tiles : n_cu;      // one persistent workgroup per CU (it owns the whole LDS)
+    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Entry point for mlp_h2f.hip's dispatcher: -> 1 when this file has an instance for (C, hid).
+int lvae_mlp_h2c_try(const lvae_mlp_desc* d, hipStream_t st, int* rc) {
+    if (d->C == 192 && d->hid == 384) { *rc = launch_h2c<192, 384>(d, st); return 1; }
+    return 0;
+}

@@ -252,9 +252,14 @@ __global__ __launch_bounds__(512, 1) void mlp_h2f_kernel(const lvae_mlp_desc d) 
 
 }  // namespace
 
+int lvae_mlp_h2c_try(const lvae_mlp_desc* d, hipStream_t st, int* rc);       // mlp_h2c.hip: the hidden-chunked form (weights streamed)
+
 extern "C" int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream) {
     if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || d->M <= 0) return -22;
-    if (d->C != F_C || d->hid != F_HID) return -22;                    // the one block shape this kernel exists for
+    if (d->C != F_C || d->hid != F_HID) {
+        int rc = 0;
+        return lvae_mlp_h2c_try(d, (hipStream_t)stream, &rc) ? rc : -22;   // -22: no fused form of this block shape
+    }
     static LdsAttr attr;
     if (const int ae = attr.ensure((const void*)mlp_h2f_kernel, F_LDS)) return ae;
     hipLaunchKernelGGL(mlp_h2f_kernel, dim3((d->M + F_BM - 1) / F_BM), dim3(512), F_LDS, (hipStream_t)stream, *d);

@@ -370,16 +370,18 @@ class Plan:
         self.flops += 2 * M * N * K
         self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)
 
-    FUSED_MLP_SHAPE = (128, 192)       # (C, hidden) of csrc/mlp_h2f.hip: the decoder's stride-4 blocks
+    # (C, hidden) block shapes whose MLP runs as ONE launch: csrc/mlp_h2f.hip (weights resident in LDS: the decoder's stride-4 blocks) and
+    # csrc/mlp_h2c.hip (hidden dimension walked in chunks, weights streamed: the encoder's stride-4 blocks)
+    FUSED_MLP_SHAPES = ((128, 192), (192, 384))
 
     def mlp_fused_ok(self, C, hid, k, n_affine=1):
-        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2f.hip)?  A rule in the block's shape only; its bits are the
-        two-launch path's (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms)."""
-        return (C, hid) == self.FUSED_MLP_SHAPE and self.mlp_h2p_ok(C, hid, k, n_affine, None)
+        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2f.hip / mlp_h2c.hip)?  A rule in the block's shape only; its bits
+        are the two-launch path's (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms)."""
+        return (C, hid) in self.FUSED_MLP_SHAPES and self.mlp_h2p_ok(C, hid, k, n_affine, None)
 
     def mlp_fused(self, *, y, M, C, hid, w1, b1, w2, b2, gamma, res, out, label='mlp'):
         """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2): lvae_mlp_h2f."""
-        assert self.prec == 4 and (C, hid) == self.FUSED_MLP_SHAPE
+        assert self.prec == 4 and (C, hid) in self.FUSED_MLP_SHAPES and M * C * 4 < 2 ** 31
         w1h, w2h = self.w16_k32.get(w1), self.w16_k32.get(w2)
         assert w1h and w2h, f'{label}: weights do not fit the pre-split operand format'
         d = _native.MlpDesc()

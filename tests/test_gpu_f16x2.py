@@ -301,6 +301,41 @@ def test_gemm_h2p_serial_split_k_equals_parallel_split_k(M, N, K, S, epi):
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
 
+@pytest.mark.parametrize('M', [128, 1000, 300 * 128 + 5, 98304, 196608])
+def test_mlp_h2c_equals_two_gemms(M):
+    """The hidden-chunked fused MLP of the C = 192 / hidden = 384 blocks (csrc/mlp_h2c.hip: a persistent workgroup per CU walks the hidden
+    dimension in chunks of 128 -- fc1 stages, GELU / split into LDS, fc2 stages -- with every operand streamed by LDS-DMA through one flat
+    ring) against the two pre-split GEMM launches it replaces: every output bit equal.  M = 128: one tile; 1000 / 38405: ragged last
+    tile, fewer tiles than CUs / more than one tile per workgroup; 98304 / 196608: the model's launches (384 / 768 tiles: several tiles
+    per persistent workgroup, the ring running across tile boundaries).  In place (out aliasing the residual) like the plans use it."""
+    from lvae import _native
+    from lvae.models.base import pack_f16x2_k32
+    C, HID = 192, 384
+    g = torch.Generator().manual_seed(M)
+    yf = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    yf[3] = 0.0
+    W1 = (torch.randn(HID, C, generator=g) / C ** 0.5).cuda()
+    W2 = (torch.randn(C, HID, generator=g) / HID ** 0.5).cuda()
+    b1, b2, gamma = torch.randn(HID, generator=g).cuda(), torch.randn(C, generator=g).cuda(), torch.rand(C, generator=g).cuda()
+    res = torch.randn(M, C, generator=g).cuda()
+    y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+    hid = torch.empty(M, HID, device='cuda')                           # H2K32 planes, 4 bytes per element
+    ref = torch.full((M, C), float('nan'), device='cuda')
+    assert _gemm(y, C, C, W1, w1h, b1, hid, HID, M, 1, a_h2=1, out_h2=1) == 0
+    assert _gemm(hid, HID, HID, W2, w2h, b2, ref, C, M, 2, gamma=gamma, res=res, a_h2=1) == 0
+    d = _native.MlpDesc()
+    out = res.clone()                                                # in place: out aliases the residual
+    d.y, d.w1, d.b1, d.w2, d.b2, d.gamma = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr()
+    d.res, d.out, d.M, d.C, d.hid = out.data_ptr(), out.data_ptr(), M, C, HID
+    for rep in range(3):                                              # repeated launches: nothing may depend on what the last one left in LDS
+        out.copy_(res)
+        assert _native.lib().lvae_mlp_h2f(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        assert not torch.isnan(ref).any() and torch.equal(out, ref), f'rep {rep}: {int((out != ref).sum())} of {out.numel()} elements differ'
+    ref64 = res.double() + gamma.double() * (F.gelu(yf.double() @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double())
+    assert float((out.double() - ref64).abs().max()) < 1e-4 * float(ref64.abs().max())
+
+
 @pytest.mark.parametrize('M', [128, 1000, 24576 + 77, 98304])
 def test_mlp_h2f_equals_two_gemms(M):
     """The fused MLP of the C = 128 / hidden = 192 blocks (csrc/mlp_h2f.hip: fc1 -> GELU -> fc2 in one launch, the hidden tile in LDS)

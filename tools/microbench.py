@@ -143,7 +143,7 @@ def mlpf():
     """C = 128 / hidden = 192 MLP (decoder stride-4 blocks): two pre-split GEMM launches against the fused kernel (csrc/mlp_h2f.hip)."""
     from lvae._native import MlpDesc
     from lvae.models.base import pack_f16x2_k32
-    C, HID = 128, 192
+    C, HID = (int(v) for v in os.environ.get('LVAE_MLP_SHAPE', '128,192').split(','))
     for M in (196608, 98304, 49152, 24576):
         yf = torch.randn(M, C, device='cuda')
         W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
