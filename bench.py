@@ -302,6 +302,8 @@ def main():
     def dominant(fn, a, label):
         """The dominant kernel = every launch of gemm_kernel<*, PLAIN> (the dense channel-mixing GEMMs: MLP fc1/fc2, i.e. 87%
         of the path's FLOPs, plus post_merge / prior / z_proj / upsample 1x1 convs) -- one rocprofv3 kernel-name family."""
+        if fn is _nat.lib().lvae_mlp_h2f:           # fc1 -> GELU -> fc2 of a block as ONE launch (csrc/mlp_h2f.hip, mlp_h2c.hip): same family, same MFMA stream
+            return True
         if fn is not _nat.lib().lvae_gemm_f32:
             return False
         return _ct.cast(a[0], _ct.POINTER(_nat.GemmDesc)).contents.a_mode == _nat.A_PLAIN
@@ -354,6 +356,9 @@ def main():
     def any_gemm(fn, a, label):
         return fn is _nat.lib().lvae_gemm_f32
 
+    def any_plain_gemm(fn, a, label):
+        return fn is _nat.lib().lvae_gemm_f32 and dominant(fn, a, label)
+
     # whole-step algorithmic GEMM FLOPs (every GEMM launch of the encode + decode plans of the timed configuration)
     timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
     step_gflop = sum(2.0 * d.M * d.N * d.K for d in gemm_descs(timed_plans, any_gemm)) / 1e9
@@ -394,8 +399,18 @@ def main():
             del pl.run                                   # back to Plan.run
         model.native_group_loops = True
         ms, n_launch = timer.summary()
-        per_step = sum(2 * d.M * d.N * d.K for d in gemm_descs(single, dominant))
-        alg_bytes = sum(alg_bytes_of(d) for d in gemm_descs(single, dominant))
+        from lvae._native import MlpDesc as _MlpDesc
+
+        def fused_descs(plans):
+            for _, pl in plans:
+                for fn, a, label, _side in pl.ops:
+                    if fn is _nat.lib().lvae_mlp_h2f:
+                        yield ctypes.cast(a[0], ctypes.POINTER(_MlpDesc)).contents
+        per_step = (sum(2 * d.M * d.N * d.K for d in gemm_descs(single, any_plain_gemm)) +
+                    sum(4 * m.M * m.C * m.hid for m in fused_descs(single)))
+        # fused launches: y + residual + result once (4 bytes per element each), both weight matrices once; the hidden map never leaves the CU
+        alg_bytes = (sum(alg_bytes_of(d) for d in gemm_descs(single, any_plain_gemm)) +
+                     sum(12 * m.M * m.C + 8 * m.C * m.hid for m in fused_descs(single)))
         flops = per_step * args.roofline_steps
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         gbs = alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -414,7 +429,8 @@ def main():
                     'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         elif args.precision == 'f16x2':
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0           # fp16 MFMA peak = bf16 MFMA peak; 3 MFMAs per fp32-accurate product step
-            roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + '
+            roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + mlp_h2c_kernel / mlp_h2f_kernel '
+                                               '(fc1 -> GELU -> fc2 of the stride-4 blocks as one launch: counted as its two GEMMs, 4 M C hid flop) + '
                                                'gemm_h2_kernel<TN, *, 0> (the other PLAIN GEMM launches); v_mfma_f32_32x32x16_f16 x 3 cross terms',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'peak_note': '2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product step (hi*hi, hi*lo, lo*hi of a 2-term '

@@ -23,12 +23,35 @@
 #include <type_traits>
 #include <utility>
 
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2C_EXP_NOGELU) || defined(H2C_EXP_NOADMA) || defined(H2C_EXP_NOWDMA) || defined(H2C_EXP_NOMFMA) || \
+    defined(H2C_EXP_NOEPI) || defined(H2C_EXP_NODSR) || defined(H2C_EXP_NOBAR) || defined(H2C_EXP_TRACE))
+#error "H2C_EXP_* ablations (wrong results by construction: they remove work to time what is left) need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
+#endif
+// H2C_EXP_TRACE: in-kernel timeline (s_memtime) of wave 0 of workgroup 0 on its SECOND tile, written behind the output rows
+// (out + M * C floats; tools/microbench.py mlptrace allocates the room): slot 3P .. 3P + 2 = before the counted wait / before the barrier /
+// behind the barrier of position P; 96 + 2 ch .. = GELU phase of chunk ch begins / ends; 104 .. 106 = epilogue begins / next tile's stages
+// landed / stores issued
+#ifdef H2C_EXP_TRACE
+#define H2C_T(slot) do { if (trace_on) trace[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define H2C_T(slot) do { } while (0)
+#endif
+#ifdef H2C_EXP_NOMFMA
+#define H2C_MFMA(a, b, c) (c)
+#else
+#define H2C_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef H2C_EXP_NODSR
+#define H2C_DSR(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
+#else
 #define H2C_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -84,8 +107,13 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     const int perm = (pp ^ ((4 * (wave & 1) + (r_in >> 1)) & 7)) << 4;
     const int dvA = r_in * (C * 4) + perm;               // A / W1 rows are C * 4 bytes (H2K32)
     const int dvW2 = r_in * (HID * 4) + perm;            // W2 rows are HID * 4 bytes
+#ifdef H2C_EXP_NOWDMA
+    const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w1, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w2, 0, 0, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w1, 0, HID * C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w2, 0, C * HID * 4, 0x00020000);
+#endif
     // issue the DMA instructions of tile-relative position P (compile time) of the tile whose A rows start at `abase` (`arows` valid rows;
     // 0 rows = nothing to fetch: every lane out of range, the slot is zero-filled -- keeps the instruction count, hence vmcnt, uniform)
     auto dma_pos = [&](auto ptag, int i, const char* abase, int arows) __attribute__((always_inline)) {
@@ -97,6 +125,9 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         const int g = i * 8 + wv;
         if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. 127 | W1 rows CH * 128 .. + 127, k32 index Q
             if (i < 2) {
+#ifdef H2C_EXP_NOADMA
+                arows = 0;
+#endif
                 const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, arows * (C * 4), 0x00020000);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA, 8 * g * (C * 4) + Q * 128, 0, 0);
             } else {
@@ -138,8 +169,21 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     }
 
     f32x16 oH[NB2], oX[NB2], pH[2], pX[2];
+    // fragments of a stage's SECOND k16 step are read in the middle of the stage and consumed at the start of the NEXT stage of the same
+    // kind (fc1 / fc2), behind that stage's barrier: its first MFMAs are then ready the moment the barrier opens, and cover the latency
+    // of its own first fragment reads (eight waves reading at once: ~200 cycles during which the matrix pipe used to idle, 30 times a tile)
+    f16x8 ca[2], cw[NB2 > 2 ? NB2 : 2][2];                                  // carried: A planes, W blocks x planes
+    f32x4 rv[4][NB2];                                                        // residual rows of this tile (requested four stages early)
     bool first = true;
+#ifdef H2C_EXP_TRACE
+    unsigned long long* trace = (unsigned long long*)(d.out + (long)d.M * C);
+    int tile_no = 0;
+#endif
     for (; tile < n_tiles; tile += gridDim.x) {
+#ifdef H2C_EXP_TRACE
+        const bool trace_on = blockIdx.x == 0 && tid == 0 && tile_no == 1;
+        ++tile_no;
+#endif
         const int m0 = tile * BM;
         const int nxt = tile + gridDim.x;
         const char* ab_cur = tile_abase(tile);
@@ -154,6 +198,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         static_for<NP>([&](auto ptag) {
             constexpr int P = decltype(ptag)::value, CH = P / PT, Q = P % PT, SL = P % S::NBUF;
             constexpr bool F = Q < KS1;
+            constexpr bool RUN_FIRST = Q == 0 || Q == KS1, RUN_LAST = Q == KS1 - 1 || Q == PT - 1;
+            constexpr int NB = F ? 2 : NB2;                                  // W blocks of this stage's wave tile
             constexpr int P2 = P + 2;                                        // the position whose DMAs are issued during this stage
             constexpr int NI2 = S::ni(P2);
             const char* ab2 = P2 >= NP ? ab_nxt : ab_cur;
@@ -164,146 +210,151 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { pH[b][r] = 0.f; pX[b][r] = 0.f; }
             }
-            // ---- my DMA instructions of this position have landed once only those of position P + 1 are outstanding; after the barrier
-            // everyone's have, and everyone is done with position P - 1.
-            // Positions 0 and 1 of a tile that follows another one were waited for before that tile's epilogue stores (below).
+            // ---- my DMA instructions of this position have landed once only those of position P + 1 are outstanding (+ the residual
+            // rows, requested behind the last chunk's GELU phase: younger than the DMAs of its first two G stages); after the barrier
+            // everyone's have, and everyone is done with position P - 1 -- fragment reads included (lgkmcnt: the slot of position P - 1 is
+            // the target of the DMAs issued below).  Positions 0 and 1 of a tile that follows another one were waited for before that
+            // tile's epilogue stores.
+            H2C_T(3 * P);
             if (P >= 2 || first) {
-                constexpr int ALLOW = S::ni(P + 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+                constexpr int ALLOW = S::ni(P + 1) + ((CH == S::NCH - 1 && (Q == KS1 || Q == KS1 + 1)) ? 4 * NB2 : 0);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ALLOW) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            H2C_T(3 * P + 1);
+#ifndef H2C_EXP_NOBAR
             asm volatile("s_barrier" ::: "memory");
+#endif
+            H2C_T(3 * P + 2);
             LVAE_FENCE();
             int issued = 0;
-            if constexpr (F) {
-                // ---- fc1 stage: P[32 x 64] += A[32 x 32k] W1[64 x 32k]^T
-                f16x8 af[2][2], wf[2][2][2];                                  // [t][plane], [t][b][plane]
-                // (opaque: the per-slot, per-piece addresses are recomputed per stage -- four v_add in MFMA shadows -- instead of being
-                //  hoisted out of the tile loop as ~30 loop-invariant registers, which hipcc then spills)
-                unsigned aq = a_row + SL * S::SLOT, wq = w1_row + SL * S::SLOT;
-                asm volatile("" : "+v"(aq), "+v"(wq));
+            // (opaque: the per-slot, per-piece addresses are recomputed per stage -- a few v_add in MFMA shadows -- instead of being hoisted
+            //  out of the tile loop as ~30 loop-invariant registers, which hipcc then spills)
+            unsigned aq = F ? a_row + SL * S::SLOT : h_row + (Q - KS1) * (BM * 128);
+            unsigned wq = (F ? w1_row : w2_row) + SL * S::SLOT;
+            asm volatile("" : "+v"(aq), "+v"(wq));
+            const unsigned* pa = F ? po : ph;                                 // piece offsets of the A side (hidden chunk: rot3 permutation)
+            // one k16 step's MFMAs (three groups: X += a_lo' w_hi | X += a_hi w_lo' | H += a_hi w_hi, per accumulator in gemm_h2p's order),
+            // one DMA instruction of position P + 2 behind each group
+            auto mfma_step = [&](const f16x8 (&a)[2], const f16x8 (*w)[2]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    H2C_DSR(af[t][0], aq + po[0 + t], 0);
-                    H2C_DSR(af[t][1], aq + po[2 + t], 0);
+                for (int j = 0; j < 3; ++j) {
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        H2C_DSR(wf[t][b][0], wq + po[0 + t], b * 4096);
-                        H2C_DSR(wf[t][b][1], wq + po[2 + t], b * 4096);
+                    for (int b = 0; b < NB; ++b) {
+                        if constexpr (F) {
+                            if (j == 0) pX[b] = H2C_MFMA(a[1], w[b][0], pX[b]);
+                            else if (j == 1) pX[b] = H2C_MFMA(a[0], w[b][1], pX[b]);
+                            else pH[b] = H2C_MFMA(a[0], w[b][0], pH[b]);
+                        } else {
+                            if (j == 0) oX[b] = H2C_MFMA(a[1], w[b][0], oX[b]);
+                            else if (j == 1) oX[b] = H2C_MFMA(a[0], w[b][1], oX[b]);
+                            else oH[b] = H2C_MFMA(a[0], w[b][0], oH[b]);
+                        }
                     }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (t == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]));
+                    if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
                     LVAE_FENCE();
+                }
+            };
+            // first k16 step of this stage -> fresh registers
+            f16x8 fa[2], fw[NB][2];
+            H2C_DSR(fa[0], aq + pa[0], 0);
+            H2C_DSR(fa[1], aq + pa[2], 0);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
+            for (int b = 0; b < NB; ++b) {
+                H2C_DSR(fw[b][0], wq + po[0], b * 4096);
+                H2C_DSR(fw[b][1], wq + po[2], b * 4096);
+            }
+            LVAE_FENCE();
+            if constexpr (!RUN_FIRST) mfma_step(ca, cw);                      // the previous stage's second step (fragments carried)
+            if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[1][0]), "+v"(fw[1][1]), "+v"(fw[2][0]), "+v"(fw[2][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[1][0]), "+v"(fw[1][1]));
+            LVAE_FENCE();
+            // second k16 step -> the carried registers (their last readers, the MFMAs above, have been issued)
+            H2C_DSR(ca[0], aq + pa[1], 0);
+            H2C_DSR(ca[1], aq + pa[3], 0);
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            if (j == 0) pX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][1], wf[t][b][0], pX[b], 0, 0, 0);
-                            else if (j == 1) pX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][1], pX[b], 0, 0, 0);
-                            else pH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][0], pH[b], 0, 0, 0);
-                        }
-                        if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
-                        LVAE_FENCE();
+            for (int b = 0; b < NB; ++b) {
+                H2C_DSR(cw[b][0], wq + po[1], b * 4096);
+                H2C_DSR(cw[b][1], wq + po[3], b * 4096);
+            }
+            LVAE_FENCE();
+            mfma_step(fa, fw);
+            if constexpr (RUN_LAST) {
+                if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[1][0]), "+v"(cw[1][1]), "+v"(cw[2][0]), "+v"(cw[2][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[1][0]), "+v"(cw[1][1]));
+                LVAE_FENCE();
+                mfma_step(ca, cw);
+            }
+            static_assert(S::NI_F <= 6 && S::NI_G <= 6, "DMA instructions of a stage must fit behind the MFMA groups of two k16 steps");
+#pragma unroll
+            for (int i2 = 0; i2 < 6; ++i2)                                    // (a run's first stage has three groups only)
+                if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+            if constexpr (Q == KS1 - 1) {
+                // ---- GELU phase: hidden chunk = split(gelu(P + b1)) -> LDS in the stage layout of an A operand (row m of stage
+                // c / 32: 64 B hi | 64 B lo', 16-B pieces permuted).  After the quad transpose a lane holds 4 consecutive columns of a row.
+                // (opaque lane coordinates: the 16 store addresses of this phase are recomputed here instead of living -- spilled --
+                //  across the whole tile loop)
+                int lio = li, lho = lh;
+                asm volatile("" : "+v"(lio), "+v"(lho));
+                const int lj = lio & 3;
+                H2C_T(96 + 2 * CH);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int cs = 2 * wn + b;                                // hidden columns 64 wn + 32 b .. + 31 of the chunk = stage cs
+                    const int cc = lio & ~3;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v0 = __builtin_fmaf(pX[b][4 * g + 0], 1.0f / 2048.0f, pH[b][4 * g + 0]) + b1v[CH][b];
+                        float v1 = __builtin_fmaf(pX[b][4 * g + 1], 1.0f / 2048.0f, pH[b][4 * g + 1]) + b1v[CH][b];
+                        float v2 = __builtin_fmaf(pX[b][4 * g + 2], 1.0f / 2048.0f, pH[b][4 * g + 2]) + b1v[CH][b];
+                        float v3 = __builtin_fmaf(pX[b][4 * g + 3], 1.0f / 2048.0f, pH[b][4 * g + 3]) + b1v[CH][b];
+#ifdef H2C_EXP_NOGELU
+                        unsigned h0 = __float_as_uint(v0), l0 = __float_as_uint(v1), h1 = __float_as_uint(v2), l1 = __float_as_uint(v3);
+#else
+                        gelu_erf2(v0, v1); gelu_erf2(v2, v3);
+                        quad_transpose(v0, v1, v2, v3, lj);
+                        unsigned h0, l0, h1, l1;
+                        split_pair_h2(v0, v1, h0, l0);
+                        split_pair_h2(v2, v3, h1, l1);
+#endif
+                        const int m = 32 * wm + 4 * lho + 8 * g + lj;
+                        const int k = (m >> 1) & 7, x = ((k << 1) & 7) | (k >> 2);
+                        const unsigned base = lds0 + S::RING + cs * (BM * 128) + m * 128 + ((cc & 7) << 1);
+                        const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 0) ^ x) << 4)), "v"(hi2) : "memory");
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 4) ^ x) << 4)), "v"(lo2) : "memory");
                     }
                 }
-                static_assert(S::NI_F <= 6 && S::NI_G <= 6, "DMA instructions per stage must fit behind the MFMA groups of a stage");
-                if constexpr (Q == KS1 - 1) {
-                    // ---- GELU phase: hidden chunk = split(gelu(P + b1)) -> LDS in the stage layout of an A operand (row m of stage
-                    // c / 32: 64 B hi | 64 B lo', 16-B pieces permuted).  After the quad transpose a lane holds 4 consecutive columns of a row.
-                    // (opaque lane coordinates: the 16 store addresses of this phase are recomputed here instead of living -- spilled --
-                    //  across the whole tile loop)
-                    int lio = li, lho = lh;
-                    asm volatile("" : "+v"(lio), "+v"(lho));
-                    const int lj = lio & 3;
+                H2C_T(97 + 2 * CH);
+                if constexpr (CH == S::NCH - 1) {
+                    // the tile's residual rows, requested now (the P accumulators are dead: their registers hold the 4 * NB2 vectors), four
+                    // fc2 stages before the epilogue adds them -- their latency under load (2 - 4 us) used to be exposed once per tile
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int cs = 2 * wn + b;                            // hidden columns 64 wn + 32 b .. + 31 of the chunk = stage cs
-                        const int cc = lio & ~3;
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = m0 + 32 * wm + 4 * lho + 8 * g + lj;
+                        const int rbg = (row < d.M ? row : 0) * C;            // (M * C < 2^31: checked on the host)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            float v0 = __builtin_fmaf(pX[b][4 * g + 0], 1.0f / 2048.0f, pH[b][4 * g + 0]) + b1v[CH][b];
-                            float v1 = __builtin_fmaf(pX[b][4 * g + 1], 1.0f / 2048.0f, pH[b][4 * g + 1]) + b1v[CH][b];
-                            float v2 = __builtin_fmaf(pX[b][4 * g + 2], 1.0f / 2048.0f, pH[b][4 * g + 2]) + b1v[CH][b];
-                            float v3 = __builtin_fmaf(pX[b][4 * g + 3], 1.0f / 2048.0f, pH[b][4 * g + 3]) + b1v[CH][b];
-                            gelu_erf2(v0, v1); gelu_erf2(v2, v3);
-                            quad_transpose(v0, v1, v2, v3, lj);
-                            unsigned h0, l0, h1, l1;
-                            split_pair_h2(v0, v1, h0, l0);
-                            split_pair_h2(v2, v3, h1, l1);
-                            const int m = 32 * wm + 4 * lho + 8 * g + lj;
-                            const int k = (m >> 1) & 7, x = ((k << 1) & 7) | (k >> 2);
-                            const unsigned base = lds0 + S::RING + cs * (BM * 128) + m * 128 + ((cc & 7) << 1);
-                            const u32x2_t hi2 = {h0, h1}, lo2 = {l0, l1};
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 0) ^ x) << 4)), "v"(hi2) : "memory");
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(base + ((((cc >> 3) + 4) ^ x) << 4)), "v"(lo2) : "memory");
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my part of the hidden chunk is in LDS before the next barrier
-                }
-            } else {
-                // ---- fc2 stage: O[32 x C/2] += H[32 x 32k] W2[C/2 x 32k]^T
-                constexpr int G = Q - KS1;
-                f16x8 af[2][2], wf[2][NB2][2];
-                unsigned aq = h_row + G * (BM * 128), wq = w2_row + SL * S::SLOT;
-                asm volatile("" : "+v"(aq), "+v"(wq));
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    H2C_DSR(af[t][0], aq + ph[0 + t], 0);
-                    H2C_DSR(af[t][1], aq + ph[2 + t], 0);
-#pragma unroll
-                    for (int b = 0; b < NB2; ++b) {
-                        H2C_DSR(wf[t][b][0], wq + po[0 + t], b * 4096);
-                        H2C_DSR(wf[t][b][1], wq + po[2 + t], b * 4096);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (t == 0) {
-                        if constexpr (NB2 == 3) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]), "+v"(wf[0][2][0]), "+v"(wf[0][2][1]));
-                        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0][0]), "+v"(wf[0][0][1]), "+v"(wf[0][1][0]), "+v"(wf[0][1][1]));
-                    } else {
-                        if constexpr (NB2 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]), "+v"(wf[1][2][0]), "+v"(wf[1][2][1]));
-                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0][0]), "+v"(wf[1][0][1]), "+v"(wf[1][1][0]), "+v"(wf[1][1][1]));
-                    }
-                    LVAE_FENCE();
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-#pragma unroll
-                        for (int b = 0; b < NB2; ++b) {
-                            if (j == 0) oX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][1], wf[t][b][0], oX[b], 0, 0, 0);
-                            else if (j == 1) oX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][1], oX[b], 0, 0, 0);
-                            else oH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][0], wf[t][b][0], oH[b], 0, 0, 0);
-                        }
-                        if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
-                        LVAE_FENCE();
+                        for (int b = 0; b < NB2; ++b)
+#ifdef H2C_EXP_NOEPI
+                            rv[g][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
+                            rv[g][b] = *(const f32x4*)(d.res + rbg + wn * (C / 2) + 32 * b + (lio & ~3));
+#endif
                     }
                 }
             }
         });
         first = false;
 
-        // ---- epilogue 2: out = res + gamma * (O + b2)   (gemm_epilogue's order: + bias, * gamma, transpose, + residual).  The residual
-        // rows are requested first; then the next tile's first two stages (in flight since the last two G stages) are waited for HERE,
-        // before the stores: a counted vmcnt behind a store burst would make the next stages wait for the stores to drain.
+        // ---- epilogue 2: out = res + gamma * (O + b2)   (gemm_epilogue's order: + bias, * gamma, transpose, + residual).  The next tile's
+        // first two stages (in flight since the last two G stages) are waited for HERE, before the stores: a counted vmcnt behind a store
+        // burst would make the next stages wait for the stores to drain.
         {
             int lio = li, lho = lh;
             asm volatile("" : "+v"(lio), "+v"(lho));
             const int lj = lio & 3;
-            // every residual row is requested before anything is stored (the P accumulators are dead: their registers hold the 4 * NB2
-            // residual vectors): with stores in flight hipcc waits for a load with vmcnt(0), i.e. for the stores to drain
-            f32x4 rv[4][NB2];
-            int rb[4];
-            bool rok[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = m0 + 32 * wm + 4 * lho + 8 * g + lj;
-                rok[g] = row < d.M;
-                rb[g] = (rok[g] ? row : 0) * C;                             // (M * C < 2^31: checked on the host)
-#pragma unroll
-                for (int b = 0; b < NB2; ++b) rv[g][b] = *(const f32x4*)(d.res + rb[g] + wn * (C / 2) + 32 * b + (lio & ~3));
-            }
+            H2C_T(104);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -316,18 +367,27 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                     oH[b][4 * g + 0] = v0; oH[b][4 * g + 1] = v1; oH[b][4 * g + 2] = v2; oH[b][4 * g + 3] = v3;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // residual rows here; next tile's positions 0 and 1 landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (residual rows long here;) next tile's positions 0 and 1 landed
+            H2C_T(105);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const int row = m0 + 32 * wm + 4 * lho + 8 * g + lj;       // (recomputed: the rows of the residual request, not kept in registers)
+                const bool rokg = row < d.M;
+                const int rbg = (rokg ? row : 0) * C;
 #pragma unroll
                 for (int b = 0; b < NB2; ++b) {
-                    if (rok[g]) {
+#ifdef H2C_EXP_NOEPI
+                    if (rokg && oH[b][4 * g] == 123.456f) {
+#else
+                    if (rokg) {
+#endif
                         f32x4 o = {oH[b][4 * g + 0], oH[b][4 * g + 1], oH[b][4 * g + 2], oH[b][4 * g + 3]};
                         o[0] += rv[g][b][0]; o[1] += rv[g][b][1]; o[2] += rv[g][b][2]; o[3] += rv[g][b][3];
-                        *(f32x4*)(d.out + rb[g] + wn * (C / 2) + 32 * b + (lio & ~3)) = o;
+                        *(f32x4*)(d.out + rbg + wn * (C / 2) + 32 * b + (lio & ~3)) = o;
                     }
                 }
             }
+            H2C_T(106);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -209,6 +209,38 @@ def mlppanel():
         print(f'C={C} hid={HID} M={M}: ' + '  '.join(f'P={p}: {t:7.1f} us ({base / t:4.2f}x)' for p, t in row) + f'   [{4.0 * M * C * HID / (min(t for _, t in row) * 1e-6) / 1e12:.0f} TF/s best]')
 
 
+def mlptrace():
+    """In-kernel timeline of csrc/mlp_h2c.hip (experimental build with -DH2C_EXP_TRACE, LVAE_LIB=...): wave 0 of workgroup 0, second tile."""
+    from lvae._native import MlpDesc
+    from lvae.models.base import pack_f16x2_k32
+    C, HID, M = 192, 384, int(os.environ.get('LVAE_TRACE_M', '196608'))
+    yf = torch.randn(M, C, device='cuda')
+    W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
+    b1, b2, gamma = torch.randn(HID, device='cuda'), torch.randn(C, device='cuda'), torch.rand(C, device='cuda')
+    res = torch.randn(M, C, device='cuda')
+    out = torch.zeros(M * C + 4096, device='cuda')
+    y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+    m = MlpDesc()
+    m.y, m.w1, m.b1, m.w2, m.b2, m.gamma, m.res, m.out = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr(), res.data_ptr(), out.data_ptr()
+    m.M, m.C, m.hid = M, C, HID
+    for _ in range(5):
+        L.lvae_mlp_h2f(ctypes.byref(m), st())
+    torch.cuda.synchronize()
+    t = out[M * C:].view(torch.int64)[:128].cpu().numpy().astype('int64')
+    t0 = t[0]
+    PT, KS1 = 10, 6
+    print('pos kind : wait_dma  barrier  stage(behind barrier -> next stage begins)   [cycles, s_memtime]')
+    for P in range(30):
+        nxt = t[3 * (P + 1)] if P < 29 else t[104]
+        kind = ('F%d' % (P % PT)) if P % PT < KS1 else ('G%d' % (P % PT - KS1))
+        extra = ''
+        if P % PT == KS1 - 1:
+            ch = P // PT
+            extra = f'   incl. GELU phase {t[97 + 2 * ch] - t[96 + 2 * ch]}'
+        print(f'{P:3d} {kind:3s} : {t[3 * P + 1] - t[3 * P]:8d} {t[3 * P + 2] - t[3 * P + 1]:8d} {nxt - t[3 * P + 2]:8d}{extra}')
+    print(f'epilogue: compute {t[105] - t[104]} (incl. wait for the next tile\'s first stages), stores {t[106] - t[105]};  tile total {t[106] - t0} cycles')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'gemmx':
         gemmx()
@@ -218,6 +250,8 @@ if __name__ == '__main__':
         mlpf()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mlppanel':
         mlppanel()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mlptrace':
+        mlptrace()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk':
         for b in (1, 2, 4, 8, 16):
             gemmsk(b)
