@@ -41,7 +41,7 @@
 
 // Timing studies (WRONG RESULTS by construction; tools/build_exp.sh builds only): LVAE_EXP_DW_NODMA re-reads the tile's first two rows
 // instead of fetching new ones (what is left without the row traffic), LVAE_EXP_DW_NOLN skips the LayerNorm phases and stores.
-#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_DW_NODMA) || defined(LVAE_EXP_DW_NOLN) || defined(LVAE_EXP_DW_NOREAD) || defined(LVAE_EXP_DW_LN_AT))
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(LVAE_EXP_DW_NODMA) || defined(LVAE_EXP_DW_NOLN) || defined(LVAE_EXP_DW_NOREAD) || defined(LVAE_EXP_DW_LN_AT) || defined(LVAE_EXP_DW_PKHI))
 #error "LVAE_EXP_DW_* experiment hooks need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh); never in liblvae_hip.so"
 #endif
 
@@ -90,12 +90,22 @@ __device__ __forceinline__ unsigned f2bf_rne(float x) {
 // whose GEMMs are MFMA-dense enough), 0 of 400 alone; as src0 (`op_sel:[1,0,0]`) 0 of 1600 -- not trusted either: hipcc never emits
 // that selection for packed f32 arithmetic, and the scalar form costs 2 %; its `v_pk_mov_b32 ... op_sel:[1,0]` for a pair assembled from two odd halves
 // is the same selection, so those pairs are assembled with two v_mov_b32 here.  tests/test_gpu_kernels.py::test_dwconv_ln_beside_gemms.
+// Round 4 settled it at ISA level: tools/ubench/pk_opsel_probe.hip (50 lines: chains of `v_pk_fma_f32 ... op_sel:[0,1,0]` against the
+// same chain in scalar v_fma_f32, an MFMA-only kernel on a second stream) -> profiles/r04_ubench_pk_opsel_erratum_probe.txt:
+// 832 - 1360 wrong LOW-lane results in 1.0e11 chains with the selection on src1 beside the MFMA kernel, 0 alone; 0 with the selection on
+// src0, 0 in the high lane, 0 for the op_sel_hi-only broadcast used here.  A hardware erratum (MI355X, ROCm 7.2), not a race of this
+// kernel.  An all-packed tap loop on the (clean) src0 form was measured too (-DLVAE_EXP_DW_PKHI: profiles/r04_dw_bench_all_packed_taps_ab.txt):
+// 90.2 -> 87.5 us on the 128x192x192 map, -3 ... -8 % on the k = 7 layers -- not worth standing next to an erratum for.
 __device__ __forceinline__ void pk_fma_wlo(f32x2& a, f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(x), "v"(w));
 }
 __device__ __forceinline__ void fmac_whi(f32x2& a, float x0, float x1, f32x2 w) {
     asm("v_fmac_f32 %0, %1, %2" : "+v"(a[0]) : "v"(x0), "v"(w[1]));
     asm("v_fmac_f32 %0, %1, %2" : "+v"(a[1]) : "v"(x1), "v"(w[1]));
+}
+// the all-packed form: the weight in the HIGH half of its pair, broadcast to both lanes (op_sel: the low lane selects the high dword)
+__device__ __forceinline__ void pk_fma_whi(f32x2& a, f32x2 x, f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(x), "v"(w));
 }
 __device__ __forceinline__ f32x2 pair_of(float lo, float hi) {     // two plain moves (never v_pk_mov_b32 with op_sel)
     f32x2 p;
@@ -377,7 +387,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
                         const int tap = i * KS + j;
                         if (!PACKW) pk_fma_wlo(acc[th][q / 2], xv, wp[tap]);
                         else if (tap % 2 == 0) pk_fma_wlo(acc[th][q / 2], xv, wp[tap / 2]);
+#ifdef LVAE_EXP_DW_PKHI
+                        else pk_fma_whi(acc[th][q / 2], xv, wp[tap / 2]);
+#else
                         else fmac_whi(acc[th][q / 2], x0, x1, wp[tap / 2]);
+#endif
                     }
                 }
             }
