@@ -94,8 +94,8 @@ __device__ __forceinline__ unsigned f2bf_rne(float x) {
 // same chain in scalar v_fma_f32, an MFMA-only kernel on a second stream) -> profiles/r04_ubench_pk_opsel_erratum_probe.txt:
 // 832 - 1360 wrong LOW-lane results in 1.0e11 chains with the selection on src1 beside the MFMA kernel, 0 alone; 0 with the selection on
 // src0, 0 in the high lane, 0 for the op_sel_hi-only broadcast used here.  A hardware erratum (MI355X, ROCm 7.2), not a race of this
-// kernel.  An all-packed tap loop on the (clean) src0 form was measured too (-DLVAE_EXP_DW_PKHI: profiles/r04_dw_bench_all_packed_taps_ab.txt):
-// 90.2 -> 87.5 us on the 128x192x192 map, -3 ... -8 % on the k = 7 layers -- not worth standing next to an erratum for.
+// kernel.  What an all-packed tap loop would buy was timed as well (-DLVAE_EXP_DW_PKHI, timing only: profiles/r04_dw_bench_all_packed_taps_ab.txt):
+// 90.2 -> 87.5 us on the 128x192x192 map, -3 ... -8 % on the k = 7 layers -- too little to stand next to an erratum for, even on the src0 form.
 __device__ __forceinline__ void pk_fma_wlo(f32x2& a, f32x2 x, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(x), "v"(w));
 }
