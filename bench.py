@@ -445,7 +445,7 @@ def main():
                                  f'peak this launch family runs at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}', **common}
         # HBM bytes per launch of this family: NOT measured in this run (hardware counters cannot be read from inside the process);
         # copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command
-        tfile = {('f16x2', 8, 512, 768): 'r03_pmc_gemm_traffic.json', ('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r03_pmc_gemm_traffic_fp8_1216.json',
+        tfile = {('f16x2', 8, 512, 768): 'r04_pmc_gemm_traffic.json', ('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r03_pmc_gemm_traffic_fp8_1216.json',
                  ('fp8', 8, 512, 768): 'r02_pmc_gemm_traffic_fp8.json'}.get((args.precision, B, H, W))
         tp = os.path.join(REPO, 'profiles', tfile) if tfile else None
         if tp and not os.path.exists(tp) and args.precision == 'bf16x3':

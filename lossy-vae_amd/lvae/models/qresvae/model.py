@@ -403,6 +403,15 @@ class _QresPlan(Plan):
         pk, lib = self.pk, self.lib
         C, k, hid = m.dim, m.kernel_size, m.hidden
         M = self.B * H * W
+        if self.mlp_fused_ok(C, hid, k):
+            # C = 192 / hidden = 384 (the stride-4 blocks of qres34m, encoder and decoder): fc1 -> GELU -> fc2 as one launch (csrc/mlp_h2c.hip),
+            # the bits of the two launches below
+            y = self.buf('y', M * C)
+            self.add(lib.lvae_dwconv_ln_h2, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), pk.p(p + '.ln_w'), pk.p(p + '.ln_b'), None, None,
+                                             y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
+            self.mlp_fused(y=y.data_ptr(), M=M, C=C, hid=hid, w1=pk.p(p + '.fc1_w'), b1=pk.p(p + '.fc1_b'), w2=pk.p(p + '.fc2_w'),
+                           b2=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'), res=x, out=out, label=p + '.mlp')
+            return
         y, hbuf = self.buf('y', M * C), self.buf('hid', M * hid)
         pre1, pre2, S1, S2 = self.mlp_pipeline(C, hid, k, H * W)        # f16x2 plans: pre-split y / hidden map (see the qarv plan's cnx)
         self.add(lib.lvae_dwconv_ln_h2 if pre1 else lib.lvae_dwconv_ln_f32,

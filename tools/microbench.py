@@ -252,6 +252,8 @@ if __name__ == '__main__':
         mlppanel()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mlptrace':
         mlptrace()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk_b':
+        gemmsk(int(sys.argv[2]))
     elif len(sys.argv) > 1 and sys.argv[1] == 'gemmsk':
         for b in (1, 2, 4, 8, 16):
             gemmsk(b)

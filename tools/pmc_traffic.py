@@ -47,7 +47,7 @@ def main(fetch_db, write_db, out_json=None):
     for name, n, fm, wm in rows[:40]:
         print(f'{short(name):78s} {n:8d} {fm:16.2f} {2 * fm:10.2f} {wm:16.2f}')
     fam = [r for r in rows if (re.search(r'gemm(_x3|_bf16)?_kernel', r[0]) and r[0].rstrip().endswith(', 0>(lvae_gemm_desc, int, int)'))
-           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<', r[0])]
+           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<|mlp_h2c_kernel<|mlp_h2f_kernel', r[0])]
     n = sum(r[1] for r in fam)
     if n:
         fm = sum(r[1] * r[2] for r in fam) / n
