@@ -30,7 +30,20 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// timing ablations (wrong results by construction; tools/build_exp.sh only): what a launch costs without its MFMAs / fragment reads / epilogue
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2P_EXP_NOMFMA) || defined(H2P_EXP_NODSR) || defined(H2P_EXP_NOEPI) || defined(H2P_EXP_NODMA))
+#error "H2P_EXP_* ablations need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
+#endif
+#ifdef H2P_EXP_NODSR
+#define H2P_DSR(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
+#else
 #define H2P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
+#ifdef H2P_EXP_NOMFMA
+#define H2P_MFMA(a, b, c) (c)
+#else
+#define H2P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 
 // FOLD ("serial split-K", d.ksplit = S > 1 with a_h2): ONE workgroup walks the S contiguous K slices of its tile and adds their partial sums
 // in slice order -- tot = P_0; tot += P_1; ... with P_s = accH_s + accX_s / 2048 -- then applies splitk_epilogue_store: the operations
@@ -82,7 +95,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
     auto dma = [&](int i, int stage, int buf) {                     // i, buf: compile-time after unrolling; stage: uniform
         const int g = i * NWAVE + wave;
         const bool isA = g < BM / 8;                                // uniform
+#ifdef H2P_EXP_NODMA
+        const int soff = 0x7ffffff0;                                  // out of range: the DMA writes zeros, no memory traffic
+#else
         const int soff = (isA ? 8 * g : 8 * g - BM) * rowb + stage * 128;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsW, (__attribute__((address_space(3))) void*)((char*)smem + buf * STAGE + g * 1024),
                                                  16, dvoff, soff, 0, 0);
     };
@@ -180,14 +197,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (j == 0) {
-                        accX[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][1], bf[tt][b][0], accX[0][b], 0, 0, 0);
-                        accX[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][1], bf[tt][b][0], accX[1][b], 0, 0, 0);
+                        accX[0][b] = H2P_MFMA(af[tt][0][1], bf[tt][b][0], accX[0][b]);
+                        accX[1][b] = H2P_MFMA(af[tt][1][1], bf[tt][b][0], accX[1][b]);
                     } else if (j == 1) {
-                        accX[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][0], bf[tt][b][1], accX[0][b], 0, 0, 0);
-                        accX[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][0], bf[tt][b][1], accX[1][b], 0, 0, 0);
+                        accX[0][b] = H2P_MFMA(af[tt][0][0], bf[tt][b][1], accX[0][b]);
+                        accX[1][b] = H2P_MFMA(af[tt][1][0], bf[tt][b][1], accX[1][b]);
                     } else {
-                        accH[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][0][0], bf[tt][b][0], accH[0][b], 0, 0, 0);
-                        accH[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tt][1][0], bf[tt][b][0], accH[1][b], 0, 0, 0);
+                        accH[0][b] = H2P_MFMA(af[tt][0][0], bf[tt][b][0], accH[0][b]);
+                        accH[1][b] = H2P_MFMA(af[tt][1][0], bf[tt][b][0], accH[1][b]);
                     }
                     // one DMA instruction of stage s + NBUF - 1 behind each MFMA pair until all NI are out
                     if (issued < NI) { dma(issued, sn, NXT); ++issued; }
@@ -228,7 +245,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(c
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accH[a][b][r] = __builtin_fmaf(accX[a][b][r], 1.0f / 2048.0f, accH[a][b][r]);
+#ifdef H2P_EXP_NOEPI
+    if (accH[0][0][0] == 123.456f) d.out[0] = accH[0][0][1] + accH[1][TN - 1][3];
+#else
     gemm_finish<C>(d, accH, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
+#endif
 }
 
 template <int WM, int TN, int NBUF, bool FOLD = false>

@@ -360,6 +360,51 @@ def test_config4_sharded_eval_real_model_two_ranks(offline_home):
     assert res == single, (res, single)
 
 
+# CLIC-2022-test shaped set (30 images drawn from {2048x1365, 1365x2048, 2048x1152, 1536x2048}; here 32, the
+# sizes scaled by 1/4 so that eight ranks sharing ONE GPU finish in a minute): (h, w) per image
+CLIC_SHAPES_FULL = [(1365, 2048)] * 14 + [(2048, 1365)] * 8 + [(1152, 2048)] * 6 + [(2048, 1536)] * 4
+
+
+def test_config4_eight_ranks_clic_shaped_set_and_lpt_balance(offline_home, tmp_path_factory):
+    """The 8-rank layout of BASELINE config 4, rehearsed on one GPU: 8 gloo ranks sharing cuda:0, the REAL qarv_base, a 32-image set
+    with the CLIC-2022 size mix -> the same dict, to the last bit, as the single-process imcoding_evaluate; and the LPT partition of the
+    FULL-size set is balanced: predicted makespan / mean load <= 1.1 (rank::world on the sorted file list: checked to be no better)."""
+    import torch.multiprocessing as mp
+    import lvae
+    from lvae.evaluation import imcoding_evaluate, lpt_partition
+    pad = lambda v: (v + 63) // 64 * 64
+    costs = [pad(h) * pad(w) for h, w in CLIC_SHAPES_FULL]
+    parts = lpt_partition(costs, 8)
+    assert sorted(i for p_ in parts for i in p_) == list(range(32))
+    loads = [sum(costs[i] for i in p_) for p_ in parts]
+    imbalance = max(loads) / (sum(loads) / 8.0)
+    naive = [sum(costs[i] for i in range(r, 32, 8)) for r in range(8)]
+    print(f'LPT partition of the CLIC-shaped set over 8 ranks: predicted imbalance {imbalance:.3f} (rank::world: {max(naive) / (sum(naive) / 8.0):.3f})')
+    assert imbalance <= 1.1 and imbalance <= max(naive) / (sum(naive) / 8.0) + 1e-9
+    root = tmp_path_factory.mktemp('clic32')
+    rng_sizes = [(h // 4, w // 4) for h, w in CLIC_SHAPES_FULL]
+    order = [(i * 13) % 32 for i in range(32)]                      # file order != size order
+    _write_pngs(str(root / 'clic32'), [rng_sizes[i] for i in order], 900)
+    ckpt = str(offline_home / 'torch_home' / 'hub' / 'checkpoints' / 'qarv_base-2022-dec-12.pt')
+    m = lvae.get_model('qarv_base', pretrained=ckpt).to('cuda:0').eval()
+    m.compress_mode()
+    m.default_lmb = 256.0
+    single = imcoding_evaluate(m, str(root / 'clic32'))
+    del m
+    torch.cuda.empty_cache()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 27100 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 8, str(root / 'clic32'), ckpt, port, q)) for r in range(8)]
+    for p_ in procs:
+        p_.start()
+    res = q.get(timeout=900)
+    for p_ in procs:
+        p_.join(timeout=300)
+        assert p_.exitcode == 0
+    assert res == single, (res, single)
+
+
 def test_config4_eval_sharded_script_and_bench_two_ranks(offline_home, tmp_path):
     """scripts/eval-sharded.py and `bench.py --gpus 2` launched by torch.distributed.run exactly as the driver does, in their
     documented 1-GPU rehearsal mode (all ranks on cuda:0, gloo instead of RCCL)."""
