@@ -246,9 +246,14 @@ def _lossless_pixel_guard(pl, g, sym, idx, h, w):
     for pos in zip(*np.nonzero(sym != g['out.symbols'])):
         sa, sb = int(sym[pos]), int(g['out.symbols'][pos])
         assert abs(sa - sb) == 1, (pos, sa, sb)
-        va, vb = m_hip[pos] * 127.5 + 127.5, m_ref[pos] * 127.5 + 127.5                      # the value torch.round sees (:72)
-        assert abs(np.rint(va) - np.rint(vb)) == 1, (pos, va, vb)                             # the two rounded means are neighbours
-        half = (np.rint(va) + np.rint(vb)) / 2.0
+        va, vb = m_hip[pos] * 127.5 + 127.5, m_ref[pos] * 127.5 + 127.5                      # the value torch.round sees (:72), exactly
+        # ... and as both sides compute it: two fp32 operations, then round-half-even (a value that lands ON the half-integer in fp32 goes to
+        # the even neighbour, whatever its exact value was)
+        f32 = np.float32
+        ra = np.rint(f32(f32(f32(m_hip[pos]) * f32(127.5)) + f32(127.5)))
+        rb = np.rint(f32(f32(f32(m_ref[pos]) * f32(127.5)) + f32(127.5)))
+        assert abs(float(ra) - float(rb)) == 1, (pos, va, vb, ra, rb)                         # the two rounded means are neighbours
+        half = (float(ra) + float(rb)) / 2.0
         mg = max(abs(va - half), abs(vb - half))
         st['sym_flips'] += 1
         st['worst_sym_margin'] = max(st['worst_sym_margin'], float(mg))
