@@ -362,7 +362,7 @@ def main():
     # whole-step algorithmic GEMM FLOPs (every GEMM launch of the encode + decode plans of the timed configuration)
     timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
     step_gflop = sum(2.0 * d.M * d.N * d.K for d in gemm_descs(timed_plans, any_gemm)) / 1e9
-    from lvae._native import MlpDesc                        # + the fused fc1 -> GELU -> fc2 launches (csrc/mlp_h2f.hip): two GEMMs each
+    from lvae._native import MlpDesc                        # + the fused fc1 -> GELU -> fc2 launches (csrc/mlp_h2c.hip): two GEMMs each
     for _, pl in timed_plans:
         for fn, a, label, _side in pl.ops:
             if fn is _nat.lib().lvae_mlp_h2f:
@@ -429,7 +429,7 @@ def main():
                     'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **common}
         elif args.precision == 'f16x2':
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0           # fp16 MFMA peak = bf16 MFMA peak; 3 MFMAs per fp32-accurate product step
-            roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + mlp_h2c_kernel / mlp_h2f_kernel '
+            roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + mlp_h2c_kernel<C, hid, chunk> '
                                                '(fc1 -> GELU -> fc2 of the stride-4 blocks as one launch: counted as its two GEMMs, 4 M C hid flop) + '
                                                'gemm_h2_kernel<TN, *, 0> (the other PLAIN GEMM launches); v_mfma_f32_32x32x16_f16 x 3 cross terms',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),

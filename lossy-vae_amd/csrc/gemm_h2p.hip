@@ -280,6 +280,10 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
 int lvae_gemm_h2pp_launch(const lvae_gemm_desc* d, hipStream_t st, int tn);        // gemm_h2pp.hip: the persistent-form study (force = 92 / 91)
 #endif
 
+#ifdef LVAE_EXP_H2E
+int lvae_gemm_h2e_try(const lvae_gemm_desc* d, hipStream_t st, int* rc);          // gemm_h2e.hip: the epilogue-interleaved study (force = 51)
+#endif
+
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
     if (d->prec != 4 || !d->a_h2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || d->K0 != d->K || (d->K & 31) || d->lda0 != d->K ||
         d->ldw != d->K || d->a_gelu || (long)256 * d->K * 4 > 0x7fffffffL)
@@ -293,6 +297,12 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
         return 1;
     }
     int sel = force;
+#ifdef LVAE_EXP_H2E
+    if (sel == 51) {
+        if (lvae_gemm_h2e_try(d, st, rc)) return 1;
+        sel = 0;
+    }
+#endif
 #ifdef LVAE_EXP_H2PP
     if ((sel == 92 || sel == 91) && d->K >= 128 && !(d->K & 63)) { *rc = lvae_gemm_h2pp_launch(d, st, sel - 90); return 1; }
 #endif

@@ -1,23 +1,28 @@
-// mlp_h2c.hip -- the MLP of a ConvNeXt block as ONE persistent kernel for block shapes whose weights do NOT fit a CU's LDS
-// (f16x2 arithmetic, pre-split operands):      out = x + gamma * ( fc2( gelu( fc1(y) + b1 ) ) + b2 )      (lvae/models/common.py:131-132,154-158)
-// -- first of all the encoder's seven stride-4 blocks, C = 192 / hidden = 384 (qarv/zoo.py:38-40).  As two launches (gemm_h2p.hip) such a
-// block writes and re-reads its hidden map through HBM (302 MB each way at batch 8: the two launches run at 2.3 / 3.4 TB/s and
-// 146 / 164 TFLOP/s, profiles/r03_op_times_*), and every tile's GELU / split / store epilogue is serial with its short main loop
-// (K = 192: six 32-deep stages).  Here a workgroup (8 waves, 128 rows) walks the hidden dimension in chunks of 128 and keeps the
-// chunk on the CU:
-//   per chunk:  P[128 x 128] = y W1_c^T over K = C        (C/32 "F" stages: A rows + the chunk's W1 rows, 32 KB per stage)
-//               H = split(gelu(P + b1_c)) -> LDS           (64 KB, stage layout of an A operand)
-//               O[128 x C] += H W2_c^T over K = 128        (4 "G" stages: the chunk's W2 columns, C x 128 B per stage)
+// mlp_h2c.hip -- the MLP of a ConvNeXt block as ONE persistent kernel (f16x2 arithmetic, pre-split operands):
+//     out = x + gamma * ( fc2( gelu( fc1(y) + b1 ) ) + b2 )                      (lvae/models/common.py:131-132,154-158)
+// for the stride-4 blocks: the encoder's seven with C = 192 / hidden = 384 (qarv/zoo.py:38-40) and the decoder's eight with C = 128 /
+// hidden = 192 (qarv/zoo.py:86-87: the GPU tail of every decode -- after the last latent block nothing else is left to overlap with).  As
+// two launches (gemm_h2p.hip) such a block writes and re-reads its hidden map through HBM (302 / 151 MB each way at batch 8: the two
+// launches run at 2.3 / 3.4 TB/s and 146 / 164 TFLOP/s, profiles/r03_op_times_*), and every tile's GELU / split / store epilogue is
+// serial with its short main loop (K = 192: six 32-deep stages).  Here a workgroup (8 waves, 128 rows) walks the hidden dimension in
+// chunks of HC (128; 64 for hidden = 192) and keeps the chunk on the CU:
+//   per chunk:  P[128 x HC] = y W1_c^T over K = C          (C/32 "F" stages: A rows + the chunk's W1 rows)
+//               H = split(gelu(P + b1_c)) -> LDS           (HC/32 stages of 128 rows x 128 B: the stage layout of an A operand)
+//               O[128 x C] += H W2_c^T over K = HC         (HC/32 "G" stages: the chunk's W2 columns, C x 128 B per stage)
 //   per tile:   out = res + gamma * (O + b2)
 // All global -> LDS traffic is LDS-DMA (`buffer_load ... lds`, whole 128-B lines, source-side swizzle: gemm_h2p.hip) through ONE ring of
-// three 32 KB slots that runs flat across F stages, G stages, chunks and TILES (the workgroup is persistent: the next tile's first two
+// three slots that runs flat across F stages, G stages, chunks and TILES (the workgroup is persistent: the next tile's first two
 // stages are in flight while this tile's epilogue stores drain), two stages ahead, one raw s_barrier + counted vmcnt per stage.
 // Every (tile-relative) stage position is compile-time -- the whole tile is unrolled -- so ring slots, LDS offsets and the vmcnt
-// allowances are immediates.  LDS: 3 x 32 KB ring + 64 KB hidden chunk = the CU's 160 KB.
-// Arithmetic per element is the two-launch path's, operation for operation (mlp_h2f.hip says how): per accumulator the MFMA sequence of
-// gemm_h2p_kernel (k16 steps ascending -- chunks and G stages ascend in the hidden index), fma(accX, 2^-11, accH), the same epilogue
-// roundings, the same split -- so every output bit equals fc2(fc1(.)) through gemm_h2p (tests/test_gpu_f16x2.py::
-// test_mlp_h2c_equals_two_gemms) and the host may use it for this block shape at every batch size.
+// allowances are immediates.  LDS: 3 x 32 KB ring + 64 KB hidden chunk = the CU's 160 KB (192 / 384); 3 x 24 + 32 KB (128 / 192).
+// Arithmetic per element is the two-launch path's, operation for operation: per accumulator the MFMA sequence of gemm_h2p_kernel (k16
+// steps ascending -- chunks and G stages ascend in the hidden index; X: a_lo' w_hi, a_hi w_lo'; H: a_hi w_hi), fma(accX, 2^-11, accH),
+// gemm_epilogue's "+ bias -> gelu" / "+ bias, * gamma, + residual" with the same roundings (no contraction), the same split_pair_h2 --
+// so every output bit equals fc2(fc1(.)) through gemm_h2p (tests/test_gpu_f16x2.py::test_mlp_h2c_equals_two_gemms,
+// test_mlp_h2f_equals_two_gemms) and the host may use it for these block shapes at every batch size.
+// (Round 3's form for 128 / 192 -- mlp_h2f_kernel: one tile per workgroup, A and ALL of W1 fetched first, five phases in series, waves
+//  waiting 47 % of their cycles -- is superseded by the <128, 192, 64> instance: same bits, 141 -> 122 us at M = 196608,
+//  profiles/r04_mlp_h2c_128x192_vs_mlp_h2f.txt.)
 #include "gemm_common.h"
 
 #include <type_traits>
@@ -58,33 +63,45 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-template <int C_, int HID_>
+template <int C_, int HID_, int HC_>
 struct H2C {
-    static constexpr int C = C_, HID = HID_, BM = 128, HC = 128;
+    static constexpr int C = C_, HID = HID_, BM = 128, HC = HC_;   // HC: hidden chunk (128; 64 where 128 does not divide the hidden width)
     static constexpr int NCH = HID / HC;                 // hidden chunks per tile
     static constexpr int KS1 = C / 32, KS2 = HC / 32;    // F / G stages per chunk
     static constexpr int PT = KS1 + KS2;                 // stage positions per chunk
     static constexpr int NP = NCH * PT;                  // ... per tile
+    static constexpr int NBF = HC / 64;                  // hidden column blocks of a wave in an F stage (wave tile 32 x HC/2)
     static constexpr int NB2 = C / 64;                   // output column blocks of a wave (wave tile 32 x C/2)
-    static constexpr int SLOT = 32 * 1024, NBUF = 3, RING = NBUF * SLOT;
-    static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: 4 stages of 128 rows x 128 B
+    static constexpr int NBM = NBF > NB2 ? NBF : NB2;
+    static constexpr int SLOT = ((BM + HC) > C ? (BM + HC) : C) * 128, NBUF = 3, RING = NBUF * SLOT;   // a stage: 128 A rows + HC W1 rows | C W2 rows
+    static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: HC / 32 stages of 128 rows x 128 B
     static constexpr int LDS = RING + HBYTES;
     static constexpr int NI_F = (BM + HC) / 64;          // DMA instructions per wave: F stage (A rows + W1 rows; 8 rows each, 8 waves)
     static constexpr int NI_G = C / 64;                  // ... G stage (C rows of W2)
-    static_assert(HID % HC == 0 && C % 64 == 0 && NP % NBUF == 0, "shape");
-    static_assert(C * 128 <= SLOT && LDS <= 160 * 1024, "LDS");
+    static_assert(HID % HC == 0 && HC % 64 == 0 && C % 64 == 0 && NP % NBUF == 0 && NBM <= 3, "shape");
+    static_assert(LDS <= 160 * 1024, "LDS");
     static constexpr bool is_f(int p) { return (p % PT) < KS1; }
     static constexpr int ni(int p) { return is_f(p % NP) ? NI_F : NI_G; }
 };
 
-template <int C_, int HID_>          // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
+// wait for a k16 step's fragment reads (a_[2], w_[NB][2]) -- the asm names them as operands so that no MFMA that reads them moves above it
+template <int NB>
+__device__ __forceinline__ void h2c_frags_landed(f16x8 (&a)[2], f16x8 (*w)[2]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NB == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(w[0][0]), "+v"(w[0][1]));
+    else if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
+#endif
+}
+
+template <int C_, int HID_, int HC_> // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
 __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, int n_tiles) {
     // (device pass only: hipcc's HOST pass cannot instantiate the generic lambdas below -- the kernel template then silently drops out
     //  of overload resolution and no launch stub is emitted; the host needs nothing but the stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang fp contract(off)
-    using S = H2C<C_, HID_>;
-    constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2;
+    using S = H2C<C_, HID_, HC_>;
+    constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2, NBF = S::NBF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,13 +110,13 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((char*)smem);
 
     // per-column parameters of this lane's output columns (requested before the DMA queue fills: loads retire in order)
-    float b2v[NB2], gmv[NB2], b1v[S::NCH][2];
+    float b2v[NB2], gmv[NB2], b1v[S::NCH][NBF];
 #pragma unroll
     for (int b = 0; b < NB2; ++b) { b2v[b] = d.b2[wn * (C / 2) + 32 * b + li]; gmv[b] = d.gamma[wn * (C / 2) + 32 * b + li]; }
 #pragma unroll
     for (int ch = 0; ch < S::NCH; ++ch)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) b1v[ch][b] = d.b1[ch * S::HC + 64 * wn + 32 * b + li];       // fc1 bias of this lane's hidden columns, every chunk
+        for (int b = 0; b < NBF; ++b) b1v[ch][b] = d.b1[ch * S::HC + 32 * NBF * wn + 32 * b + li];   // fc1 bias of this lane's hidden columns, every chunk
 
     // ---- DMA side: instruction g of an operand block covers its rows 8g .. 8g + 7 (one 128-B line each); wave w issues g = i * 8 + w,
     // so g has the parity of w and the source permutation ((row >> 1) & 7 = (4 (w & 1) + (r_in >> 1)) & 7) is a per-lane constant
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         int wv = wave;
         asm volatile("" : "+s"(wv));
         const int g = i * 8 + wv;
-        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. 127 | W1 rows CH * 128 .. + 127, k32 index Q
+        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. 127 | W1 rows CH * HC .. + HC - 1, k32 index Q
             if (i < 2) {
 #ifdef H2C_EXP_NOADMA
                 arows = 0;
@@ -141,7 +158,9 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     };
 
     // fragment addresses: piece (plane p, k16 step t, lane half) = 4p + 2t + lh at ((piece ^ x) << 4) of the lane's row; the hidden
-    // chunk uses rot3 of the row permutation (mlp_h2f.hip: separates rows m and m + 2 in the ds_write_b64 pattern of the GELU phase)
+    // chunk uses rot3 of the row permutation: any bijection of (row >> 1) & 7 keeps the fragment reads conflict-free, and this one also
+    // separates rows m and m + 2 in the ds_write_b64 pattern of the GELU phase (4 rows x 4 column groups per 16 lanes), which the plain
+    // form maps to the same banks (two-way conflicts on 31 % of the LDS cycles of round 3's kernel: profiles/r03_pmc_mlp_h2f.txt)
     const int xr = (li >> 1) & 7, xh = ((xr << 1) & 7) | (xr >> 2);
     unsigned po[4], ph[4];                               // [2p + t]
 #pragma unroll
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         ph[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xh) << 4);
     }
     const unsigned a_row = lds0 + (32 * wm + li) * 128;                       // + slot: A rows of an F stage
-    const unsigned w1_row = lds0 + BM * 128 + (64 * wn + li) * 128;           // + slot: W1 rows of an F stage
+    const unsigned w1_row = lds0 + BM * 128 + (32 * NBF * wn + li) * 128;     // + slot: W1 rows of an F stage
     const unsigned w2_row = lds0 + (wn * (C / 2) + li) * 128;                 // + slot: W2 rows of a G stage
     const unsigned h_row = lds0 + S::RING + (32 * wm + li) * 128;             // + g * 16 KB: hidden rows
 
@@ -168,11 +187,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         static_for<S::NI_F>([&](auto i) { dma_pos(std::integral_constant<int, 1>{}, decltype(i)::value, ab, ar); });
     }
 
-    f32x16 oH[NB2], oX[NB2], pH[2], pX[2];
+    f32x16 oH[NB2], oX[NB2], pH[NBF], pX[NBF];
     // fragments of a stage's SECOND k16 step are read in the middle of the stage and consumed at the start of the NEXT stage of the same
     // kind (fc1 / fc2), behind that stage's barrier: its first MFMAs are then ready the moment the barrier opens, and cover the latency
     // of its own first fragment reads (eight waves reading at once: ~200 cycles during which the matrix pipe used to idle, 30 times a tile)
-    f16x8 ca[2], cw[NB2 > 2 ? NB2 : 2][2];                                  // carried: A planes, W blocks x planes
+    f16x8 ca[2], cw[S::NBM][2];                                             // carried: A planes, W blocks x planes
     f32x4 rv[4][NB2];                                                        // residual rows of this tile (requested four stages early)
     bool first = true;
 #ifdef H2C_EXP_TRACE
@@ -199,14 +218,14 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             constexpr int P = decltype(ptag)::value, CH = P / PT, Q = P % PT, SL = P % S::NBUF;
             constexpr bool F = Q < KS1;
             constexpr bool RUN_FIRST = Q == 0 || Q == KS1, RUN_LAST = Q == KS1 - 1 || Q == PT - 1;
-            constexpr int NB = F ? 2 : NB2;                                  // W blocks of this stage's wave tile
+            constexpr int NB = F ? NBF : NB2;                                // W blocks of this stage's wave tile
             constexpr int P2 = P + 2;                                        // the position whose DMAs are issued during this stage
             constexpr int NI2 = S::ni(P2);
             const char* ab2 = P2 >= NP ? ab_nxt : ab_cur;
             const int ar2 = P2 >= NP ? ar_nxt : ar_cur;
             if constexpr (Q == 0) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < NBF; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { pH[b][r] = 0.f; pX[b][r] = 0.f; }
             }
@@ -267,8 +286,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             }
             LVAE_FENCE();
             if constexpr (!RUN_FIRST) mfma_step(ca, cw);                      // the previous stage's second step (fragments carried)
-            if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[1][0]), "+v"(fw[1][1]), "+v"(fw[2][0]), "+v"(fw[2][1]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[1][0]), "+v"(fw[1][1]));
+            h2c_frags_landed<NB>(fa, fw);
             LVAE_FENCE();
             // second k16 step -> the carried registers (their last readers, the MFMAs above, have been issued)
             H2C_DSR(ca[0], aq + pa[1], 0);
@@ -281,8 +299,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             LVAE_FENCE();
             mfma_step(fa, fw);
             if constexpr (RUN_LAST) {
-                if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[1][0]), "+v"(cw[1][1]), "+v"(cw[2][0]), "+v"(cw[2][1]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[1][0]), "+v"(cw[1][1]));
+                h2c_frags_landed<NB>(ca, cw);
                 LVAE_FENCE();
                 mfma_step(ca, cw);
             }
@@ -300,8 +317,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                 const int lj = lio & 3;
                 H2C_T(96 + 2 * CH);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int cs = 2 * wn + b;                                // hidden columns 64 wn + 32 b .. + 31 of the chunk = stage cs
+                for (int b = 0; b < NBF; ++b) {
+                    const int cs = NBF * wn + b;                              // hidden columns 32 NBF wn + 32 b .. + 31 of the chunk = stage cs
                     const int cc = lio & ~3;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -394,11 +411,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #endif
 }
 
-template <int C_, int HID_>
+template <int C_, int HID_, int HC_>
 int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
-    using S = H2C<C_, HID_>;
+    using S = H2C<C_, HID_, HC_>;
     static LdsAttr attr;
-    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_>, S::LDS)) return ae;
+    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_>, S::LDS)) return ae;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -409,14 +426,16 @@ int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
     if ((long)d->M * S::C * 4 > 0x7fffffffL) return -22;    // 32-bit row offsets in the epilogue, one buffer descriptor per tile base
     const int n_tiles = (d->M + S::BM - 1) / S::BM;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;      // one persistent workgroup per CU (it owns the whole LDS)
-    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
+    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_, HC_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// Entry point for mlp_h2f.hip's dispatcher: -> 1 when this file has an instance for (C, hid).
-int lvae_mlp_h2c_try(const lvae_mlp_desc* d, hipStream_t st, int* rc) {
-    if (d->C == 192 && d->hid == 384) { *rc = launch_h2c<192, 384>(d, st); return 1; }
-    return 0;
+// fc1 -> GELU -> fc2 -> residual of one block as one launch (include/lvae_hip.h); -22: no fused form of this block shape
+extern "C" int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream) {
+    if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || d->M <= 0) return -22;
+    if (d->C == 192 && d->hid == 384) return launch_h2c<192, 384, 128>(d, (hipStream_t)stream);
+    if (d->C == 128 && d->hid == 192) return launch_h2c<128, 192, 64>(d, (hipStream_t)stream);
+    return -22;
 }

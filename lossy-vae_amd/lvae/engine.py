@@ -370,12 +370,12 @@ class Plan:
         self.flops += 2 * M * N * K
         self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)
 
-    # (C, hidden) block shapes whose MLP runs as ONE launch: csrc/mlp_h2f.hip (weights resident in LDS: the decoder's stride-4 blocks) and
-    # csrc/mlp_h2c.hip (hidden dimension walked in chunks, weights streamed: the encoder's stride-4 blocks)
+    # (C, hidden) block shapes whose MLP runs as ONE launch (csrc/mlp_h2c.hip: hidden dimension walked in chunks, weights streamed): the
+    # decoder's and the encoder's stride-4 blocks
     FUSED_MLP_SHAPES = ((128, 192), (192, 384))
 
     def mlp_fused_ok(self, C, hid, k, n_affine=1):
-        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2f.hip / mlp_h2c.hip)?  A rule in the block's shape only; its bits
+        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2c.hip)?  A rule in the block's shape only; its bits
         are the two-launch path's (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms)."""
         return (C, hid) in self.FUSED_MLP_SHAPES and self.mlp_h2p_ok(C, hid, k, n_affine, None)
 

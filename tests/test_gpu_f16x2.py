@@ -336,9 +336,9 @@ def test_mlp_h2c_equals_two_gemms(M):
     assert float((out.double() - ref64).abs().max()) < 1e-4 * float(ref64.abs().max())
 
 
-@pytest.mark.parametrize('M', [128, 1000, 24576 + 77, 98304])
+@pytest.mark.parametrize('M', [128, 1000, 24576 + 77, 98304, 196608])
 def test_mlp_h2f_equals_two_gemms(M):
-    """The fused MLP of the C = 128 / hidden = 192 blocks (csrc/mlp_h2f.hip: fc1 -> GELU -> fc2 in one launch, the hidden tile in LDS)
+    """The fused MLP of the C = 128 / hidden = 192 blocks (lvae_mlp_h2f -> csrc/mlp_h2c.hip <128, 192, 64>: fc1 -> GELU -> fc2 in one launch, hidden chunks of 64 in LDS)
     against the two pre-split GEMM launches it replaces (fc1 with the pre-split GELU epilogue, fc2 with gamma + residual): every
     output bit equal -- ragged M, wide-range rows, zero rows -- and in place (out aliasing the residual) like the plans use it."""
     from lvae import _native

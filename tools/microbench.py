@@ -140,7 +140,7 @@ def gemmsk(B=8):
 
 
 def mlpf():
-    """C = 128 / hidden = 192 MLP (decoder stride-4 blocks): two pre-split GEMM launches against the fused kernel (csrc/mlp_h2f.hip)."""
+    """C = 128 / hidden = 192 MLP (decoder stride-4 blocks): two pre-split GEMM launches against the fused kernel (csrc/mlp_h2c.hip)."""
     from lvae._native import MlpDesc
     from lvae.models.base import pack_f16x2_k32
     C, HID = (int(v) for v in os.environ.get('LVAE_MLP_SHAPE', '128,192').split(','))
@@ -159,7 +159,11 @@ def mlpf():
         m.y, m.w1, m.b1, m.w2, m.b2, m.gamma, m.res, m.out = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr(), res.data_ptr(), out.data_ptr()
         m.M, m.C, m.hid = M, C, HID
         t2 = timeit(lambda: (L.lvae_gemm_f32(ctypes.byref(d1), st()), L.lvae_gemm_f32(ctypes.byref(d2), st())))
+        two = out.clone()
+        out.zero_()
         t1 = timeit(lambda: L.lvae_mlp_h2f(ctypes.byref(m), st()))
+        torch.cuda.synchronize()
+        print(f'        fused == two launches bit for bit: {bool((out.view(torch.int32) == two.view(torch.int32)).all())}')
         print(f'M={M:7d}: fc1 + fc2 launches {t2 * 1e6:7.1f} us   fused {t1 * 1e6:7.1f} us   ({4.0 * M * C * HID / t1 / 1e12:6.1f} TF/s, {12.0 * M * C / t1 / 1e12:5.2f} TB/s of y + res + out)')
 
 
