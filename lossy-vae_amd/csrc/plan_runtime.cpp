@@ -85,6 +85,14 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
 }
 
 
+// rans_host.cpp: decode tables owned by the caller, so that the nine per-block coder calls of one decode build each table row once
+struct LvaeDecTabs;
+LvaeDecTabs* lvae_dec_tabs_new();
+void lvae_dec_tabs_free(LvaeDecTabs* t);
+int lvae_rans_decode_batch_tabs(int n_streams, const uint8_t* const* in, const size_t* in_len, const uint8_t* const* idx,
+                                const size_t* n, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                int32_t* const* sym_out, int* status, int n_threads, LvaeDecTabs* tabs);
+
 namespace {
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
@@ -102,6 +110,8 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
     std::vector<int32_t*> out_ptr(n_images);
     std::vector<size_t> cnt(n_images);
     std::vector<int> status(n_images);
+    struct TabsGuard { LvaeDecTabs* t; ~TabsGuard() { lvae_dec_tabs_free(t); } } tabs{lvae_dec_tabs_new()};
+    if (!tabs.t) return -12;
     double t_gpu = 0.0, t_coder = 0.0;
     int bad = -1;
     for (int b = 0; b < n_blocks; ++b) {
@@ -127,8 +137,8 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
             out_ptr[i] = k.sym_host + (size_t)i * k.per_image;
             cnt[i] = k.per_image;
         }
-        rc = lvae_rans_decode_batch(n_images, strings + (size_t)b * n_images, string_len + (size_t)b * n_images, idx_ptr.data(), cnt.data(),
-                                    qcdf, row_stride, cdf_len, offset, out_ptr.data(), status.data(), n_threads);
+        rc = lvae_rans_decode_batch_tabs(n_images, strings + (size_t)b * n_images, string_len + (size_t)b * n_images, idx_ptr.data(), cnt.data(),
+                                         qcdf, row_stride, cdf_len, offset, out_ptr.data(), status.data(), n_threads, tabs.t);
         if (rc != 0) {
             // a stream that does not decode: corrupt / truncated -- or decoded against garbage scale indexes because a prior parameter was
             // non-finite (the indexes themselves are always valid table rows): the status word tells the two apart

@@ -18,6 +18,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -172,9 +173,58 @@ extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t*
     return (long)nbytes;
 }
 
-extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,
-                                             const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
-                                             const int32_t* offset, int32_t* sym_out) {
+// Per-row decode tables, built lazily for the rows a stream touches (1.25 KB per row):
+//   lut[row][b] = largest s with cdf[s] <= (b << 8)                       (256 buckets of 256 counts)
+//   ent[row][b] = cdf[s] | freq(s) << 16  if the whole bucket lies inside symbol s ("pure"), else 0
+// The serial dependency of a rANS stream is  state -> cf -> symbol -> (start, freq) -> state.  Upstream's linear find_if, and
+// the first form here (bucket -> forward scan of data-dependent length -> two cdf loads), put dependent loads and a poorly
+// predictable branch into that chain for every symbol.  Most of a stream's probability mass sits in symbols much wider than a
+// bucket, so for most symbols ONE load (ent) now yields start and freq and the symbol id comes off the critical path; only
+// buckets that contain a boundary take the scan.  Measured: tools/rans_bench.py.
+// A table set belongs to ONE (qcdf, cdf_len) pair whose contents do not change while it lives.  It may be shared: by the streams of a
+// batch call (decoded concurrently: a row is built by whoever needs it first, the others wait the fraction of a microsecond that takes)
+// and by the nine per-block calls of a decode (lvae_decode_blocks) -- building the ~64 rows costs 25-35 us, which used to sit on the
+// decode chain once per latent block and stream.
+struct RowTab { uint32_t ent[256]; uint8_t lut[256]; };
+struct LvaeDecTabs {
+    RowTab tabs[256];
+    std::atomic<uint8_t> state[256];          // 0 = empty, 1 = being built, 2 = ready, 3 = invalid cdf length
+    LvaeDecTabs() { for (auto& st : state) st.store(0, std::memory_order_relaxed); }
+};
+
+namespace {
+inline void spin_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+// -> false: the row's cdf length is out of range
+inline bool ensure_row(LvaeDecTabs& D, int row, const int32_t* cdf, int32_t size) {
+    uint8_t st = D.state[row].load(std::memory_order_acquire);
+    if (st == 2) return true;
+    for (;;) {
+        if (st == 3) return false;
+        if (st == 0 && D.state[row].compare_exchange_strong(st, 1, std::memory_order_acq_rel)) break;
+        if (st == 2) return true;
+        spin_pause();
+        st = D.state[row].load(std::memory_order_acquire);
+    }
+    if (size < 2 || size > 257) { D.state[row].store(3, std::memory_order_release); return false; }
+    RowTab& T = D.tabs[row];
+    int32_t sidx = 0;
+    for (int b = 0; b < 256; ++b) {
+        const uint32_t v = (uint32_t)b << 8;
+        while (sidx + 1 < size - 1 && (uint32_t)cdf[sidx + 1] <= v) ++sidx;
+        T.lut[b] = (uint8_t)sidx;
+        const bool pure = (uint32_t)cdf[sidx + 1] >= v + 256;       // the next boundary is beyond the bucket
+        T.ent[b] = pure ? ((uint32_t)cdf[sidx] | ((uint32_t)(cdf[sidx + 1] - cdf[sidx]) << 16)) : 0u;
+    }
+    D.state[row].store(2, std::memory_order_release);
+    return true;
+}
+
+int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n, const int32_t* qcdf, int row_stride,
+                  const int32_t* cdf_len, const int32_t* offset, int32_t* sym_out, LvaeDecTabs& D) {
     if (in_len < 8 || (in_len & 3)) return -1;
     std::vector<uint32_t> tmp;
     const uint32_t* words;
@@ -185,35 +235,16 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
     uint64_t x = (uint64_t)ptr[0] | ((uint64_t)ptr[1] << 32);
     ptr += 2;
     bool overrun = false;
-    // Per-row decode tables, built lazily for the rows this stream touches (1.25 KB per row):
-    //   lut[row][b] = largest s with cdf[s] <= (b << 8)                       (256 buckets of 256 counts)
-    //   ent[row][b] = cdf[s] | freq(s) << 16  if the whole bucket lies inside symbol s ("pure"), else 0
-    // The serial dependency of a rANS stream is  state -> cf -> symbol -> (start, freq) -> state.  Upstream's linear find_if, and
-    // the first form here (bucket -> forward scan of data-dependent length -> two cdf loads), put dependent loads and a poorly
-    // predictable branch into that chain for every symbol.  Most of a stream's probability mass sits in symbols much wider than a
-    // bucket, so for most symbols ONE load (ent) now yields start and freq and the symbol id comes off the critical path; only
-    // buckets that contain a boundary take the scan.  Measured: tools/rans_bench.py.
-    struct RowTab { uint32_t ent[256]; uint8_t lut[256]; };
-    RowTab tabs[256];
-    bool have[256] = {false};
+    bool mine[256] = {false};                 // rows this stream has already seen ready (skips the atomic load in the symbol loop)
     for (size_t i = 0; i < n; ++i) {
         const int32_t row_i = idx[i];
         const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
-        const int32_t size = cdf_len[row_i];
-        const int32_t max_value = size - 2;
-        RowTab& T = tabs[row_i];
-        if (!have[row_i]) {
-            if (size < 2 || size > 257) return -4;
-            int32_t sidx = 0;
-            for (int b = 0; b < 256; ++b) {
-                const uint32_t v = (uint32_t)b << 8;
-                while (sidx + 1 < size - 1 && (uint32_t)cdf[sidx + 1] <= v) ++sidx;
-                T.lut[b] = (uint8_t)sidx;
-                const bool pure = (uint32_t)cdf[sidx + 1] >= v + 256;       // the next boundary is beyond the bucket
-                T.ent[b] = pure ? ((uint32_t)cdf[sidx] | ((uint32_t)(cdf[sidx + 1] - cdf[sidx]) << 16)) : 0u;
-            }
-            have[row_i] = true;
+        const int32_t max_value = cdf_len[row_i] - 2;
+        if (!mine[row_i]) {
+            if (!ensure_row(D, row_i, cdf, cdf_len[row_i])) return -4;
+            mine[row_i] = true;
         }
+        const RowTab& T = D.tabs[row_i];
         const uint32_t cf = (uint32_t)(x & 0xFFFF);
         const uint32_t e = T.ent[cf >> 8];
         int32_t s = T.lut[cf >> 8];
@@ -253,6 +284,14 @@ extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, c
         if (overrun) return -3;
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,
+                                             const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                             const int32_t* offset, int32_t* sym_out) {
+    std::unique_ptr<LvaeDecTabs> D(new LvaeDecTabs);
+    return decode_stream(in, in_len, idx, n, qcdf, row_stride, cdf_len, offset, sym_out, *D);
 }
 
 namespace {
@@ -373,16 +412,28 @@ extern "C" int lvae_rans_encode_batch(int n_streams, const int32_t* const* sym, 
     return rc;
 }
 
+// lvae_rans_decode_batch with caller-owned decode tables (plan_runtime.cpp: one table set for the nine per-block calls of a decode);
+// the tables must have been made for this (qcdf, cdf_len) by lvae_dec_tabs_new and die with lvae_dec_tabs_free
+LvaeDecTabs* lvae_dec_tabs_new() { return new (std::nothrow) LvaeDecTabs; }
+void lvae_dec_tabs_free(LvaeDecTabs* t) { delete t; }
+int lvae_rans_decode_batch_tabs(int n_streams, const uint8_t* const* in, const size_t* in_len, const uint8_t* const* idx,
+                                const size_t* n, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                int32_t* const* sym_out, int* status, int n_threads, LvaeDecTabs* tabs) {
+    if (n_streams < 0 || !tabs) return -22;
+    parallel_for(n_streams, n_threads, [&](int s) {
+        status[s] = decode_stream(in[s], in_len[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, sym_out[s], *tabs);
+    });
+    int rc = 0;
+    for (int s = 0; s < n_streams; ++s) if (status[s] < 0) rc = status[s];
+    return rc;
+}
+
 extern "C" int lvae_rans_decode_batch(int n_streams, const uint8_t* const* in, const size_t* in_len,
                                       const uint8_t* const* idx, const size_t* n, const int32_t* qcdf,
                                       int row_stride, const int32_t* cdf_len, const int32_t* offset,
                                       int32_t* const* sym_out, int* status, int n_threads) {
     if (n_streams < 0) return -22;
-    parallel_for(n_streams, n_threads, [&](int s) {
-        status[s] = lvae_rans_decode_with_indexes(in[s], in_len[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset,
-                                                  sym_out[s]);
-    });
-    int rc = 0;
-    for (int s = 0; s < n_streams; ++s) if (status[s] < 0) rc = status[s];
-    return rc;
+    std::unique_ptr<LvaeDecTabs> D(new (std::nothrow) LvaeDecTabs);      // shared by the streams of this call
+    if (!D) return -12;
+    return lvae_rans_decode_batch_tabs(n_streams, in, in_len, idx, n, qcdf, row_stride, cdf_len, offset, sym_out, status, n_threads, D.get());
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Idle gaps of the GPU in a rocprofv3 kernel trace (rocpd .db): union of kernel intervals over the LAST `frac` of the trace (the
-steady-state steps), the largest gaps with the kernels on either side.   gpu_gaps.py results.db [frac=0.5] [top=25]"""
+steady-state steps), the largest gaps with the kernels on either side.   gpu_gaps.py results.db [frac=0.5] [top=25]
+(frac > 1: the last `frac` MILLISECONDS of the trace instead of a fraction)"""
 import re
 import sqlite3
 import sys
@@ -16,7 +17,7 @@ def main(path, frac=0.5, top=25):
     namecol = 'display_name' if 'display_name' in scols else 'kernel_name'
     rows = sorted(cur.execute(f'select d.start, d.end, s.{namecol} from {kd} d join {ks} s on d.kernel_id = s.id').fetchall())
     t_end = rows[-1][1]
-    t0 = rows[0][0] + (t_end - rows[0][0]) * (1 - frac)
+    t0 = rows[0][0] + (t_end - rows[0][0]) * (1 - frac) if frac <= 1 else t_end - frac * 1e6
     rows = [r for r in rows if r[0] >= t0]
     busy, cs, ce, last, gaps = 0, None, None, None, []
     for a, b, n in rows:
