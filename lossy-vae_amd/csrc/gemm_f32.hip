@@ -672,6 +672,7 @@ extern "C" int lvae_gemm_num_configs(void) { return 12; }
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
 int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);        // gemm_h2.hip
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force_tile, int* rc);     // gemm_h2p.hip
+int lvae_gemm_h2n_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc);          // gemm_h2n.hip
 int lvae_gemm_launch_patch2(const lvae_gemm_desc* d, hipStream_t st);                        // gemm_f32_patch2.hip
 int lvae_gemm_launch_conv3(const lvae_gemm_desc* d, hipStream_t st);                         // gemm_f32_conv3.hip
 int lvae_gemm_lp_dispatch(const lvae_gemm_desc* d, hipStream_t st);                           // gemm_lp.hip
@@ -715,6 +716,11 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
         if (d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S)) return -22;
         return gemm_dispatch(d, st, x3v2, x3v2_tn);
     }
+    if (S > 1 && d->prec == 4 && (d->cfg == 0 || d->cfg == 3)) {
+        // narrow outputs over large maps: gemm_h2n_kernel walks the slices serially too (same bits, no workspace traffic, no reduction)
+        int rc = 0;
+        if (lvae_gemm_h2n_try(d, st, d->cfg == 3, &rc)) return rc;
+    }
     if (S > 1) {
         if (!d->ws || d->store != LVAE_ST_ROWMAJOR || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || d->K % (32 * S) ||
             (d->prec == 1 && d->K % (64 * S)))
@@ -752,7 +758,7 @@ static int gemm_dispatch_impl(const lvae_gemm_desc* d, hipStream_t st, int x3v2,
                           d->ldo != d->N || (d->ksplit > 1 && !d->a_h2)))
             return -22;
         if (d->a_h2) return lvae_gemm_h2p_try(d, st, d->cfg > 0 ? d->cfg : h2p_tile, &rc) ? rc : -22;      // cfg = 10 WM + TN: force a tile
-        return lvae_gemm_h2_try(d, st, h2_tn, &rc) ? rc : -22;
+        return lvae_gemm_h2_try(d, st, d->cfg > 0 ? d->cfg : h2_tn, &rc) ? rc : -22;                          // cfg: gemm_h2.hip's force codes
     }
     if (d->prec == 2 && x3v2 && d->cfg == 0 &&
         ((d->a_mode == LVAE_A_PLAIN && d->K0 + d->K1 == d->K) || d->a_mode == LVAE_A_CONV3)) {   // cfg -1: legacy kernel

@@ -270,8 +270,12 @@ int launch_h2(const lvae_gemm_desc* d, hipStream_t st) {
 
 // Entry point for gemm_f32.hip's dispatcher (prec 4).  Returns 1 when the problem is one this kernel takes (*rc = launch status), 0
 // otherwise -- the host (lvae/engine.py: h2_eligible) only asks for prec 4 where it is, so 0 is an argument error upstream.
-// force: 0 = choose the tile width; 1..2 = TN (tuning hook LVAE_H2_TN).  Every choice gives the same bits.
+// force (d.cfg): 0 = choose kernel and tile width; 1..2 = this kernel with that TN; 3 = gemm_h2n wherever it applies.  Every choice gives
+// the same bits.
+int lvae_gemm_h2n_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc);          // gemm_h2n.hip: narrow N over a large M
+
 int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
+    if ((force == 0 || force == 3) && lvae_gemm_h2n_try(d, st, force == 3, rc)) return 1;    // force 3: wherever that kernel can
     const bool conv3 = d->a_mode == LVAE_A_CONV3, patch2 = d->a_mode == LVAE_A_PATCH2;
     if (d->prec != 4 || (d->a_mode != LVAE_A_PLAIN && !conv3 && !patch2) || (d->K & 31) || d->ldw != d->K) return 0;
     if (patch2 && ((d->K0 & 7) || d->K != 4 * d->K0 || d->K1 != 0 || d->H <= 0 || d->W <= 0 || d->a_gelu || (long)d->M * 4 * d->K0 * 4 > 0x7ffffff0L))

@@ -86,8 +86,19 @@ def auto_ksplit(m1, N, K, store, ldo, ldres, prec):
 
 
 def h2_eligible(d):
-    """Does csrc/gemm_h2.hip (prec 4, f16x2) take this GEMM?  Mirrors lvae_gemm_h2_try."""
-    if d.K % 32 or d.ldw != d.K:
+    """Does csrc/gemm_h2.hip / gemm_h2n.hip (prec 4, f16x2) take this GEMM?  Mirrors lvae_gemm_h2_try / lvae_gemm_h2n_try: a rule in the
+    GEMM's shape only (never in M), so batched and single-image calls, encoder and decoder agree."""
+    if d.ldw != d.K:
+        return False
+    if d.K % 32:
+        # K = 16 (mod 32) -- the 3x3 convs over 48 channels of the qres bottleneck blocks: gemm_h2_kernel walks the k16 steps in pairs;
+        # the narrow-output kernel (csrc/gemm_h2n.hip: N <= 96, plain rows or the 3x3 gather) takes any whole number of them
+        if d.K % 16 or d.N > 96 or d.a_gelu or d.out_h2 or d.ksplit > 1:
+            return False
+        if d.a_mode == _native.A_PLAIN:
+            return d.K1 == 0 and d.K0 == d.K and d.lda0 % 4 == 0 and d.M * d.lda0 * 4 <= 0x7ffffff0
+        if d.a_mode == _native.A_CONV3:
+            return d.K0 % 16 == 0 and d.K == 9 * d.K0 and d.K1 == 0 and d.H > 0 and d.W > 0 and d.M * d.K0 * 4 <= 0x7ffffff0
         return False
     if d.a_mode == _native.A_PLAIN:
         if d.lda0 % 4 or d.K0 + d.K1 != d.K:
@@ -331,7 +342,7 @@ class Plan:
             if not a_h2:
                 ksplit = 1
         if self.prec == 4 and not exact and not a_h2 and not (d.prec == 4 and h2_eligible(d)):
-            # f16x2 plans: what csrc/gemm_h2.hip does not take (2x2 patch gathers, K % 32 != 0, a weight beyond fp16's range) runs on
+            # f16x2 plans: what csrc/gemm_h2.hip / gemm_h2n.hip do not take (K % 16 != 0; K = 16 mod 32 with a wide output; a weight beyond fp16's range) runs on
             # the bf16x3 arithmetic -- decided by the GEMM's shape and weights only, so encoder and decoder, batched and single-image
             # calls agree
             Wt16 = self.w16_x3.get(Wt) if self.w16_x3 is not None else None

@@ -170,12 +170,78 @@ def test_gemm_f16x2_conv3_gather(B, H, W, Cin, N, epi, a_gelu):
     assert torch.equal(one, out[b * H * W:])
 
 
+@pytest.mark.parametrize('B,H,W,Cin,N,epi,S', [(1, 50, 100, 48, 48, 1, 1), (2, 64, 96, 96, 96, 1, 1), (3, 37, 53, 48, 24, 0, 1), (2, 24, 40, 256, 8, 0, 3),
+                                               (1, 128, 192, 48, 48, 1, 1), (4, 64, 96, 384, 96, 0, 6), (8, 128, 192, 48, 48, 1, 1)])
+def test_gemm_h2n_equals_gemm_h2_conv3(B, H, W, Cin, N, epi, S):
+    """The narrow-output kernel (csrc/gemm_h2n.hip: A fragments straight from global memory, weights streamed through LDS in chunks;
+    cfg = 3 takes it wherever it applies) against gemm_h2_kernel (cfg = 1) on the 3x3-tap gather: every output bit equal -- ragged
+    last workgroup, N = 24 / 48 (partial column blocks) / 96, K = 432 (27 k16 steps: a short last weight chunk) ... 3456, and the
+    split-K launches (S = 3, 6: serial slices here, workspace + reduction there)."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(B + H + W + Cin + N)
+    M, K = B * H * W, 9 * Cin
+    x = (torch.randn(B, H, W, Cin, generator=g) * torch.exp(torch.randn(B, H, W, 1, generator=g))).cuda()
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    Wh, bias = pack_f16x2(Wt), torch.randn(N, generator=g).cuda()
+    ws = torch.empty(S * M * N, device='cuda') if S > 1 else None
+    ref = torch.full((M, N), float('nan'), device='cuda')
+    if K % 32 == 0:
+        assert _gemm(x, Cin, Cin, Wt, Wh, bias, ref, N, M, epi, a_mode=2, H=H, W=W, K=K, ksplit=S, ws=ws, cfg=1) == 0
+    else:
+        # K = 16 (mod 32): gemm_h2_kernel walks the k16 steps in pairs and does not take it; the narrow kernel is the only f16x2 form
+        # of such a layer (every batch size), so the reference is its own first launch + fp64 below
+        assert _gemm(x, Cin, Cin, Wt, Wh, bias, ref, N, M, epi, a_mode=2, H=H, W=W, K=K, cfg=1) == -22
+        assert _gemm(x, Cin, Cin, Wt, Wh, bias, ref, N, M, epi, a_mode=2, H=H, W=W, K=K) == 0
+        w4 = Wt.view(N, 3, 3, Cin).permute(0, 3, 1, 2).double()
+        r64 = F.conv2d(x.double().permute(0, 3, 1, 2), w4, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+        r64 = F.gelu(r64) if epi == 1 else r64
+        assert float((ref.double() - r64).abs().max()) < 3e-5 * max(1.0, float(r64.abs().max()))
+        one = torch.empty(H * W, N, device='cuda')                    # image b of the batch == the same image alone
+        assert _gemm(x[B - 1].contiguous(), Cin, Cin, Wt, Wh, bias, one, N, H * W, epi, a_mode=2, H=H, W=W, K=K) == 0
+        assert torch.equal(one, ref[(B - 1) * H * W:])
+    for rep in range(2):
+        out = torch.full((M, N), float('nan'), device='cuda')
+        assert _gemm(x, Cin, Cin, Wt, Wh, bias, out, N, M, epi, a_mode=2, H=H, W=W, K=K, ksplit=S, ws=ws, cfg=3) == 0
+        assert not torch.isnan(ref).any() and torch.equal(out.view(torch.int32), ref.view(torch.int32)), \
+            f'rep {rep}: {int((out.view(torch.int32) != ref.view(torch.int32)).sum())} of {out.numel()} words differ'
+
+
+@pytest.mark.parametrize('M,N,K,epi,S', [(5000, 48, 192, 1, 1), (196608, 48, 384, 1, 1), (70001, 96, 768, 1, 1), (300, 16, 64, 0, 1),
+                                         (49152, 96, 384, 3, 1), (40000, 64, 1024, 2, 4), (33000, 8, 2304, 0, 2)])
+def test_gemm_h2n_equals_gemm_h2_plain(M, N, K, epi, S):
+    """Same for plain fp32 rows (the 1x1 reductions of the qres bottleneck blocks), every epilogue, with and without split-K."""
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    A[M // 3] = 0.0
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    Wh, bias = pack_f16x2(Wt), torch.randn(N, generator=g).cuda()
+    gamma, res = torch.rand(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    ws = torch.empty(S * M * N, device='cuda') if S > 1 else None
+    ref = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, ref, N, M, epi, gamma=gamma, res=res, ksplit=S, ws=ws, cfg=1) == 0
+    out = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, out, N, M, epi, gamma=gamma, res=res, ksplit=S, ws=ws, cfg=3) == 0
+    assert not torch.isnan(ref).any() and torch.equal(out.view(torch.int32), ref.view(torch.int32)), \
+        f'{int((out.view(torch.int32) != ref.view(torch.int32)).sum())} of {out.numel()} words differ'
+    # the shape rule (cfg = 0) may pick either kernel: same bits
+    out2 = torch.full((M, N), float('nan'), device='cuda')
+    assert _gemm(A, K, K, Wt, Wh, bias, out2, N, M, epi, gamma=gamma, res=res, ksplit=S, ws=ws) == 0
+    assert torch.equal(out2.view(torch.int32), ref.view(torch.int32))
+
+
 def test_gemm_f16x2_rejects_what_it_does_not_take():
     from lvae.models.base import pack_f16x2
     A, Wt = torch.randn(64, 48).cuda(), torch.randn(32, 48).cuda()
     assert pack_f16x2(torch.full((4, 32), 1e5)) is None               # beyond fp16's range: the host keeps such a GEMM on bf16x3
     out = torch.empty(64, 32, device='cuda')
-    assert _gemm(A, 48, 48, Wt, pack_f16x2(Wt), None, out, 32, 64) == -22      # K % 32 != 0
+    assert _gemm(A, 48, 48, Wt, pack_f16x2(Wt), None, out, 32, 64) == 0        # K = 16 (mod 32), N <= 96: the narrow-output kernel (gemm_h2n.hip)
+    assert float((out.double() - A.double() @ Wt.double().t()).abs().max()) < 1e-5
+    W2 = torch.randn(200, 48).cuda()
+    out2 = torch.empty(64, 200, device='cuda')
+    assert _gemm(A, 48, 48, W2, pack_f16x2(W2), None, out2, 200, 64) == -22    # K = 16 (mod 32) with a wide output: no f16x2 kernel
+    A3, W3 = torch.randn(64, 40).cuda(), torch.randn(32, 40).cuda()
+    assert pack_f16x2(W3) is None                                              # K % 16 != 0: no f16x2 weight format
 
 
 # ---------------------------------------------------------------------------------------------- pre-split operands (csrc/gemm_h2p.hip)

@@ -1,0 +1,24 @@
+# gemm_h2n (narrow N, A straight from global memory) against gemm_h2 (cfg 1): bit-equality tests, then the shapes of qres34m / qarv_base
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/h2n
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_f16x2.py -x -q -k "h2n" 2>&1 | tail -8 | tee $O/pytest.txt
+cd /tmp
+b() { # name env... -- M N K epi
+  for cfg in 1 3 1 3; do echo -n "$1 cfg=$cfg: "; env LVAE_PREC=4 LVAE_CFG=$cfg $2 $3 timeout 120 python $R/tools/microbench.py gemm1 $4 $5 $6 $7 2>&1 | grep "us" | tail -1; done
+}
+{
+b "qres s4 3x3 48->48" LVAE_CONV3=128,192 X=1 196608 48 432 1
+b "qres s8 3x3 96->96" LVAE_CONV3=64,96 X=1 49152 96 864 1
+b "qres s4 1x1 384->48" X=1 X=1 196608 48 384 1
+b "qres s4 1x1 192->48" X=1 X=1 196608 48 192 1
+b "qres s8 1x1 768->96" X=1 X=1 49152 96 768 1
+b "qres s8 1x1 384->96" X=1 X=1 49152 96 384 1
+b "qres s4 3x3 24 (K=72: not taken)" LVAE_CONV3=128,192 X=1 196608 16 288 0
+b "qarv s8 head 3x3 256->8" LVAE_CONV3=64,96 X=1 49152 8 2304 0
+b "qarv s8 head 3x3 256->8 S=3" LVAE_CONV3=64,96 LVAE_KSPLIT=3 49152 8 2304 0
+b "qarv s16 head 3x3 384->96" LVAE_CONV3=32,48 X=1 12288 96 3456 0
+b "qarv s16 head 3x3 384->96 S=6" LVAE_CONV3=32,48 LVAE_KSPLIT=6 12288 96 3456 0
+b "qarv s8 group of 4" LVAE_CONV3=64,96 X=1 24576 8 2304 0
+} | tee $O/bench.txt

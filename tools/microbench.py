@@ -56,6 +56,19 @@ def bench_gemm(M, N, K, epi):
             d.cfg = int(os.environ['LVAE_H2P']) if int(os.environ['LVAE_H2P']) > 1 else 0
             d.out_h2 = int(os.environ.get('LVAE_OUT_H2', '0')) if epi in (0, 1) else 0
             d._keep = (ah, wh)
+    if os.environ.get('LVAE_CONV3'):                       # "H,W": 3x3-tap gather over a (M / (H W), H, W, K / 9) map
+        Hh, Ww = (int(v) for v in os.environ['LVAE_CONV3'].split(','))
+        assert K % 9 == 0 and M % (Hh * Ww) == 0
+        x = torch.randn(M, K // 9, device='cuda')
+        d.A0, d.lda0, d.K0, d.a_mode, d.H, d.W = x.data_ptr(), K // 9, K // 9, 2, Hh, Ww
+        d._keepx = x
+    if os.environ.get('LVAE_CFG'):
+        d.cfg = int(os.environ['LVAE_CFG'])
+    if int(os.environ.get('LVAE_KSPLIT', '0')) > 1:
+        S = int(os.environ['LVAE_KSPLIT'])
+        ws = torch.empty(S * M * N, device='cuda')
+        d.ksplit, d.ws = S, ws.data_ptr()
+        d._keepws = ws
     t = timeit(lambda: L.lvae_gemm_f32(ctypes.byref(d), st()))
     return t
 
