@@ -20,6 +20,15 @@
 // order, then applies splitk_epilogue_store -- the operations of the parallel form + reduction in the same order, without the workspace.
 #include "gemm_common.h"
 
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2N_EXP_CENTER) || defined(H2N_EXP_NOMFMA) || defined(H2N_EXP_NOLOAD))
+#error "H2N_EXP_* timing studies (wrong results) need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
+#endif
+#ifdef H2N_EXP_NOMFMA
+#define H2N_MFMA(a, b, c) (c)
+#else
+#define H2N_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -118,11 +127,18 @@ __global__ __launch_bounds__(512, 1) void gemm_h2n_kernel(const lvae_gemm_desc d
             int vo;
             if (AMODE == LVAE_A_CONV3) {
                 const int kq = q * 16, tap = kq / d.K0, kk = kq - tap * d.K0;                 // uniform
+#ifdef H2N_EXP_CENTER        // timing study (wrong results): every tap reads the centre pixel -- what is left when the gather's re-reads hit L1
+                const int toff = kk * 4;
+#else
                 const int toff = (((tap / 3 - 1) * d.W + (tap % 3 - 1)) * d.K0 + kk) * 4;
+#endif
                 vo = ((tapok[j] >> tap) & 1) ? a_voff[j] + toff : 0x7fffffff;
             } else {
                 vo = a_voff[j] == 0x7fffffff ? a_voff[j] : a_voff[j] + q * 64;
             }
+#ifdef H2N_EXP_NOLOAD          // timing study: the A loads of the steady state go to an out-of-range address (no memory traffic)
+            if (q >= n_d<NB>()) vo = 0x7fffffff;
+#endif
             ar[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
         }
     };
@@ -169,9 +185,9 @@ __global__ __launch_bounds__(512, 1) void gemm_h2n_kernel(const lvae_gemm_desc d
         for (int b = 0; b < NB; ++b) {
             const f16x8 whi = *(const f16x8*)(cur + b * 32 * N_WROW + b_fr + s * 64);
             const f16x8 wlo = *(const f16x8*)(cur + b * 32 * N_WROW + b_fr + s * 64 + 32);
-            accX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, accX[b], 0, 0, 0);
-            accX[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo, accX[b], 0, 0, 0);
-            accH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, accH[b], 0, 0, 0);
+            accX[b] = H2N_MFMA(alo, whi, accX[b]);
+            accX[b] = H2N_MFMA(ahi, wlo, accX[b]);
+            accH[b] = H2N_MFMA(ahi, whi, accH[b]);
         }
         if (S > 1 && ++in_slice == per) {
             // the slice's partial sum exactly as the parallel form stores it: fma(accX, 2^-11, accH), then the epilogue's "+ bias" with no
