@@ -144,9 +144,12 @@ typedef struct {
                                           /* 4: "f16x2": each fp32 operand split into hi + lo' * 2^-11 fp16 terms (23 of fp32's 24
                                                 significant bits), three cross-term fp16 MFMAs per step (hi*hi | hi*lo' + lo'*hi in a
                                                 second fp32 accumulator) -- fp32-class accuracy at half the matrix-pipe time of prec 2;
-                                                operands must stay below 65504 in magnitude.  PLAIN (incl. [A0 | A1]) and CONV3 A modes,
-                                                K % 32 == 0, ldw == K; Wt16 = [N][K/16][2][16] fp16 (lvae.models.base.pack_f16x2).
-                                                Selected by the host per GEMM (csrc/gemm_h2.hip) */
+                                                operands must stay below 65504 in magnitude.  PLAIN (incl. [A0 | A1]), CONV3 and PATCH2 A
+                                                modes, K % 32 == 0 -- or K % 16 == 0 with N <= 96, one PLAIN / CONV3 source, no a_gelu
+                                                (csrc/gemm_h2n.hip) -- ldw == K; Wt16 = [N][K/16][2][16] fp16 (lvae.models.base.pack_f16x2).
+                                                Selected by the host per GEMM (csrc/gemm_h2.hip; cfg: 0 = the library chooses kernel and
+                                                tile, 1 / 2 = gemm_h2_kernel with 64 / 128-wide tiles, 3 = gemm_h2n_kernel wherever it
+                                                applies -- every choice gives the same bits) */
     const unsigned short* Wt16;           /* prec 1: weights as bf16 bit patterns, [N][K], row stride ldw;
                                              prec 2: three such planes hi | mid | lo, plane stride N*ldw elements,
                                              followed -- when K % 32 == 0 and ldw == K -- by the same values in

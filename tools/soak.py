@@ -30,10 +30,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=120.0)
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--model', type=str, default='qarv_base', help='qarv_base (the bench model) or a qres model name (seeded weights)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
-    model, _ = bench.build_model(dev)
+    if args.model == 'qarv_base':
+        model, _ = bench.build_model(dev)
+    else:
+        import lvae
+        import seeded_init
+        model = lvae.get_model(args.model)
+        sd = model.state_dict()
+        for k in list(sd.keys()):
+            a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0, profile='typical')
+            if a is not None and 'discrete_gaussian' not in k:
+                sd[k] = torch.from_numpy(a)
+        model.load_state_dict(sd)
+        model.compress_mode()
+        model = model.to(dev).eval()
     cases = []
     for (H, W) in ((512, 768), (320, 448)):
         x = bench.synth_batch(args.batch, H, W, 0).to(dev)
@@ -68,7 +82,7 @@ def main():
         bad['decompress_single'] += int(not torch.equal(r1[0], ref_rec[i]))
         it += 1
     torch.cuda.synchronize()
-    print(json.dumps({'seconds': round(time.time() - t0, 1), 'batch': args.batch, 'sizes': [[c[0], c[1]] for c in cases],
+    print(json.dumps({'model': args.model, 'seconds': round(time.time() - t0, 1), 'batch': args.batch, 'sizes': [[c[0], c[1]] for c in cases],
                       'precision': getattr(model, '_prec', None), 'iterations': it, 'calls': counts, 'mismatches': bad,
                       'all_identical': all(v == 0 for v in bad.values())}))
     return 0 if all(v == 0 for v in bad.values()) else 1
