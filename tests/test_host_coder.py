@@ -102,6 +102,31 @@ def test_batch_api_equals_single(L, tabs):
         rans_decode_streams((cdf, ln, off), [b'\xff' * 8], [np.zeros(100, np.uint8)], [np.empty(100, np.int32)], 1)
 
 
+def test_shared_decode_tables_under_contention(L, tabs):
+    """The decoder's per-row bucket tables are one set per batch call, built lazily by whichever stream touches a row first and read
+    by all of them (csrc/rans_host.cpp: LvaeDecTabs).  Many short streams that all start on the same rows, decoded by many threads,
+    repeatedly: every stream must decode exactly as it does alone; an invalid table row must fail every stream that touches it."""
+    from lvae.models.entropy_coding import rans_decode_streams, rans_encode_streams
+    cdf, ln, off, dg = tabs
+    g = np.random.default_rng(21)
+    syms, idxs = [], []
+    for k in range(96):
+        n = int(g.integers(1, 400))
+        idx = np.concatenate([np.arange(64, dtype=np.uint8)[:min(n, 64)], g.integers(0, 64, size=max(0, n - 64)).astype(np.uint8)])
+        syms.append(np.rint(g.normal(0, 1, size=n) * dg.scale_table.numpy()[idx]).astype(np.int32)); idxs.append(idx)
+    strings = rans_encode_streams((cdf, ln, off), syms, idxs, 0)
+    alone = [_dec(L, s, i, tabs) for s, i in zip(strings, idxs)]
+    assert all(rc == 0 and np.array_equal(o, s) for (rc, o), s in zip(alone, syms))
+    for rep in range(40):
+        outs = [np.full(s.size, -12345, dtype=np.int32) for s in syms]
+        rans_decode_streams((cdf, ln, off), strings, idxs, outs, 0 if rep % 2 else 16)
+        assert all(np.array_equal(a, b) for a, b in zip(outs, syms)), rep
+    bad_ln = ln.copy()
+    bad_ln[5] = 1                                                    # a cdf row of length 1: not a distribution
+    with pytest.raises(ValueError):
+        rans_decode_streams((cdf, bad_ln, off), strings, idxs, [np.empty(s.size, dtype=np.int32) for s in syms], 16)
+
+
 def test_pmf_to_quantized_cdf_matches_oracle(L):
     g = np.random.default_rng(1)
     for n in (2, 5, 64, 248):
