@@ -284,6 +284,10 @@ int lvae_gemm_h2pp_launch(const lvae_gemm_desc* d, hipStream_t st, int tn);     
 int lvae_gemm_h2e_try(const lvae_gemm_desc* d, hipStream_t st, int* rc);          // gemm_h2e.hip: the epilogue-interleaved study (force = 51)
 #endif
 
+#ifdef LVAE_EXP_H2Q
+int lvae_gemm_h2q_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc);          // gemm_h2q.hip: the loader-wave study (force = 61)
+#endif
+
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* rc) {
     if (d->prec != 4 || !d->a_h2 || d->a_mode != LVAE_A_PLAIN || d->K1 != 0 || d->K0 != d->K || (d->K & 31) || d->lda0 != d->K ||
         d->ldw != d->K || d->a_gelu || (long)256 * d->K * 4 > 0x7fffffffL)
@@ -297,6 +301,12 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
         return 1;
     }
     int sel = force;
+#ifdef LVAE_EXP_H2Q
+    if (sel == 61) {
+        if (lvae_gemm_h2q_try(d, st, 1, rc)) return 1;
+        sel = 0;
+    }
+#endif
 #ifdef LVAE_EXP_H2E
     if (sel == 51) {
         if (lvae_gemm_h2e_try(d, st, rc)) return 1;
