@@ -63,25 +63,33 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-template <int C_, int HID_, int HC_>
+template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_>
 struct H2C {
-    static constexpr int C = C_, HID = HID_, BM = 128, HC = HC_;   // HC: hidden chunk (128; 64 where 128 does not divide the hidden width)
+    // HC: hidden chunk (128; 64 where 128 does not divide the hidden width).  BM: rows per tile (128; 64 where a 128-row output tile does
+    // not fit the registers: C = 384).  NSUB: a G stage holds the W2 rows of C / NSUB output columns (1; 3 for C = 384: 128 rows = 16 KB)
+    static constexpr int C = C_, HID = HID_, BM = BM_, HC = HC_, NSUB = NSUB_;
+    static constexpr int WMN = BM / 32, WNN = 8 / WMN;   // the eight waves as WMN x WNN wave tiles of 32 rows
     static constexpr int NCH = HID / HC;                 // hidden chunks per tile
-    static constexpr int KS1 = C / 32, KS2 = HC / 32;    // F / G stages per chunk
-    static constexpr int PT = KS1 + KS2;                 // stage positions per chunk
+    static constexpr int KS1 = C / 32, KS2 = HC / 32;    // F stages / k32 steps of fc2 per chunk
+    static constexpr int KG = KS2 * NSUB;                // G stage positions per chunk (k32 step major, column part minor)
+    static constexpr int PT = KS1 + KG;                  // stage positions per chunk
     static constexpr int NP = NCH * PT;                  // ... per tile
-    static constexpr int NBF = HC / 64;                  // hidden column blocks of a wave in an F stage (wave tile 32 x HC/2)
-    static constexpr int NB2 = C / 64;                   // output column blocks of a wave (wave tile 32 x C/2)
-    static constexpr int NBM = NBF > NB2 ? NBF : NB2;
-    static constexpr int SLOT = ((BM + HC) > C ? (BM + HC) : C) * 128, NBUF = 3, RING = NBUF * SLOT;   // a stage: 128 A rows + HC W1 rows | C W2 rows
-    static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: HC / 32 stages of 128 rows x 128 B
+    static constexpr int NBF = HC / (32 * WNN);          // hidden column blocks of a wave in an F stage (wave tile 32 x HC / WNN)
+    static constexpr int NBS = C / (NSUB * 32 * WNN);    // output column blocks of a wave in ONE G stage
+    static constexpr int NB2 = NSUB * NBS;               // output column blocks of a wave
+    static constexpr int NBM = NBF > NBS ? NBF : NBS;
+    static constexpr int SLOT = ((BM + HC) > C / NSUB ? (BM + HC) : C / NSUB) * 128, NBUF = NBUF_, RING = NBUF * SLOT;   // a stage: BM A rows + HC W1 rows | C / NSUB W2 rows
+    static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: HC / 32 stages of BM rows x 128 B
     static constexpr int LDS = RING + HBYTES;
-    static constexpr int NI_F = (BM + HC) / 64;          // DMA instructions per wave: F stage (A rows + W1 rows; 8 rows each, 8 waves)
-    static constexpr int NI_G = C / 64;                  // ... G stage (C rows of W2)
-    static_assert(HID % HC == 0 && HC % 64 == 0 && C % 64 == 0 && NP % NBUF == 0 && NBM <= 3, "shape");
+    static constexpr int LA = NBUF - 1;                  // DMA look-ahead in stage positions (3-slot ring: two; 4 slots where LDS has the room and the stages are short)
+    static constexpr int NA = BM / 64;                   // DMA instruction rounds that cover the A rows (8 rows each, 8 waves)
+    static constexpr int NI_F = (BM + HC) / 64;          // DMA instructions per wave: F stage (A rows + W1 rows)
+    static constexpr int NI_G = C / NSUB / 64;           // ... G stage (C / NSUB rows of W2)
+    static_assert(HID % HC == 0 && BM % 64 == 0 && HC % (32 * WNN) == 0 && C % (NSUB * 32 * WNN) == 0 && (C / NSUB) % 64 == 0 && NP % NBUF == 0 && NBM <= 3, "shape");
     static_assert(LDS <= 160 * 1024, "LDS");
     static constexpr bool is_f(int p) { return (p % PT) < KS1; }
     static constexpr int ni(int p) { return is_f(p % NP) ? NI_F : NI_G; }
+    static constexpr int ni_between(int p) { int n = 0; for (int x = p + 1; x < p + LA; ++x) n += ni(x); return n; }   // DMA instructions younger than position p's
 };
 
 // wait for a k16 step's fragment reads (a_[2], w_[NB][2]) -- the asm names them as operands so that no MFMA that reads them moves above it
@@ -94,25 +102,28 @@ __device__ __forceinline__ void h2c_frags_landed(f16x8 (&a)[2], f16x8 (*w)[2]) {
 #endif
 }
 
-template <int C_, int HID_, int HC_> // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
+template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_> // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
 __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, int n_tiles) {
     // (device pass only: hipcc's HOST pass cannot instantiate the generic lambdas below -- the kernel template then silently drops out
     //  of overload resolution and no launch stub is emitted; the host needs nothing but the stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang fp contract(off)
-    using S = H2C<C_, HID_, HC_>;
-    constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2, NBF = S::NBF;
+    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_>;
+    constexpr int LA = S::LA;
+    constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2, NBF = S::NBF, NBS = S::NBS, NSUB = S::NSUB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / S::WNN, wn = wave % S::WNN;
+    // first column of this wave's output block ob (ob = column part * NBS + block within the part)
+    auto col_of = [&](int ob) { return (ob / NBS) * (C / NSUB) + wn * 32 * NBS + 32 * (ob % NBS); };
     const int li = lane & 31, lh = lane >> 5;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((char*)smem);
 
     // per-column parameters of this lane's output columns (requested before the DMA queue fills: loads retire in order)
     float b2v[NB2], gmv[NB2], b1v[S::NCH][NBF];
 #pragma unroll
-    for (int b = 0; b < NB2; ++b) { b2v[b] = d.b2[wn * (C / 2) + 32 * b + li]; gmv[b] = d.gamma[wn * (C / 2) + 32 * b + li]; }
+    for (int b = 0; b < NB2; ++b) { b2v[b] = d.b2[col_of(b) + li]; gmv[b] = d.gamma[col_of(b) + li]; }
 #pragma unroll
     for (int ch = 0; ch < S::NCH; ++ch)
 #pragma unroll
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         int wv = wave;
         asm volatile("" : "+s"(wv));
         const int g = i * 8 + wv;
-        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. 127 | W1 rows CH * HC .. + HC - 1, k32 index Q
-            if (i < 2) {
+        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. BM - 1 | W1 rows CH * HC .. + HC - 1, k32 index Q
+            if (i < S::NA) {
 #ifdef H2C_EXP_NOADMA
                 arows = 0;
 #endif
@@ -149,11 +160,12 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA, 8 * g * (C * 4) + Q * 128, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA,
-                                                         (CH * S::HC + 8 * (g - 16)) * (C * 4) + Q * 128, 0, 0);
+                                                         (CH * S::HC + 8 * (g - BM / 8)) * (C * 4) + Q * 128, 0, 0);
             }
-        } else {                                         // G stage: W2 rows 0 .. C - 1, k32 index CH * 4 + (Q - KS1) of the hidden dimension
+        } else {                                         // G stage: W2 rows of column part (Q - KS1) % NSUB, k32 index CH * KS2 + (Q - KS1) / NSUB of the hidden dimension
+            constexpr int KK = (Q - KS1) / NSUB, SUB = (Q - KS1) % NSUB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvW2,
-                                                     8 * g * (HID * 4) + (CH * KS2 + (Q - KS1)) * 128, 0, 0);
+                                                     (SUB * (C / NSUB) + 8 * g) * (HID * 4) + (CH * KS2 + KK) * 128, 0, 0);
         }
     };
 
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     }
     const unsigned a_row = lds0 + (32 * wm + li) * 128;                       // + slot: A rows of an F stage
     const unsigned w1_row = lds0 + BM * 128 + (32 * NBF * wn + li) * 128;     // + slot: W1 rows of an F stage
-    const unsigned w2_row = lds0 + (wn * (C / 2) + li) * 128;                 // + slot: W2 rows of a G stage
+    const unsigned w2_row = lds0 + (wn * 32 * NBS + li) * 128;                // + slot: W2 rows of a G stage
     const unsigned h_row = lds0 + S::RING + (32 * wm + li) * 128;             // + g * 16 KB: hidden rows
 
     int tile = blockIdx.x;
@@ -183,8 +195,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     {
         const char* ab = tile_abase(tile);
         const int ar = tile_rows(tile);
-        static_for<S::NI_F>([&](auto i) { dma_pos(std::integral_constant<int, 0>{}, decltype(i)::value, ab, ar); });
-        static_for<S::NI_F>([&](auto i) { dma_pos(std::integral_constant<int, 1>{}, decltype(i)::value, ab, ar); });
+        static_for<LA>([&](auto pp) { static_for<S::NI_F>([&](auto i) { dma_pos(pp, decltype(i)::value, ab, ar); }); });
     }
 
     f32x16 oH[NB2], oX[NB2], pH[NBF], pX[NBF];
@@ -218,8 +229,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             constexpr int P = decltype(ptag)::value, CH = P / PT, Q = P % PT, SL = P % S::NBUF;
             constexpr bool F = Q < KS1;
             constexpr bool RUN_FIRST = Q == 0 || Q == KS1, RUN_LAST = Q == KS1 - 1 || Q == PT - 1;
-            constexpr int NB = F ? NBF : NB2;                                // W blocks of this stage's wave tile
-            constexpr int P2 = P + 2;                                        // the position whose DMAs are issued during this stage
+            constexpr int NB = F ? NBF : NBS;                                // W blocks of this stage's wave tile
+            constexpr int KK = F ? 0 : (Q - KS1) / NSUB;                     // G: k32 step of the chunk, and the first output block of this stage's column part
+            constexpr int OB = F ? 0 : ((Q - KS1) % NSUB) * NBS;
+            constexpr int OBP = (F || Q == KS1) ? 0 : ((Q - KS1 - 1) % NSUB) * NBS;      // ... of the previous G stage (whose second k16 step runs here)
+            constexpr int P2 = P + LA;                                       // the position whose DMAs are issued during this stage
             constexpr int NI2 = S::ni(P2);
             const char* ab2 = P2 >= NP ? ab_nxt : ab_cur;
             const int ar2 = P2 >= NP ? ar_nxt : ar_cur;
@@ -235,8 +249,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             // the target of the DMAs issued below).  Positions 0 and 1 of a tile that follows another one were waited for before that
             // tile's epilogue stores.
             H2C_T(3 * P);
-            if (P >= 2 || first) {
-                constexpr int ALLOW = S::ni(P + 1) + ((CH == S::NCH - 1 && (Q == KS1 || Q == KS1 + 1)) ? 4 * NB2 : 0);
+            if (P >= LA || first) {
+                constexpr int ALLOW = S::ni_between(P) + ((CH == S::NCH - 1 && Q >= KS1 && Q < KS1 + LA) ? 4 * NB2 : 0);
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ALLOW) : "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -250,13 +264,14 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             int issued = 0;
             // (opaque: the per-slot, per-piece addresses are recomputed per stage -- a few v_add in MFMA shadows -- instead of being hoisted
             //  out of the tile loop as ~30 loop-invariant registers, which hipcc then spills)
-            unsigned aq = F ? a_row + SL * S::SLOT : h_row + (Q - KS1) * (BM * 128);
+            unsigned aq = F ? a_row + SL * S::SLOT : h_row + KK * (BM * 128);
             unsigned wq = (F ? w1_row : w2_row) + SL * S::SLOT;
             asm volatile("" : "+v"(aq), "+v"(wq));
             const unsigned* pa = F ? po : ph;                                 // piece offsets of the A side (hidden chunk: rot3 permutation)
             // one k16 step's MFMAs (three groups: X += a_lo' w_hi | X += a_hi w_lo' | H += a_hi w_hi, per accumulator in gemm_h2p's order),
             // one DMA instruction of position P + 2 behind each group
-            auto mfma_step = [&](const f16x8 (&a)[2], const f16x8 (*w)[2]) __attribute__((always_inline)) {
+            auto mfma_step = [&](const f16x8 (&a)[2], const f16x8 (*w)[2], auto obtag) __attribute__((always_inline)) {
+                constexpr int O = decltype(obtag)::value;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
 #pragma unroll
@@ -266,9 +281,9 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                             else if (j == 1) pX[b] = H2C_MFMA(a[0], w[b][1], pX[b]);
                             else pH[b] = H2C_MFMA(a[0], w[b][0], pH[b]);
                         } else {
-                            if (j == 0) oX[b] = H2C_MFMA(a[1], w[b][0], oX[b]);
-                            else if (j == 1) oX[b] = H2C_MFMA(a[0], w[b][1], oX[b]);
-                            else oH[b] = H2C_MFMA(a[0], w[b][0], oH[b]);
+                            if (j == 0) oX[O + b] = H2C_MFMA(a[1], w[b][0], oX[O + b]);
+                            else if (j == 1) oX[O + b] = H2C_MFMA(a[0], w[b][1], oX[O + b]);
+                            else oH[O + b] = H2C_MFMA(a[0], w[b][0], oH[O + b]);
                         }
                     }
                     if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                 H2C_DSR(fw[b][1], wq + po[2], b * 4096);
             }
             LVAE_FENCE();
-            if constexpr (!RUN_FIRST) mfma_step(ca, cw);                      // the previous stage's second step (fragments carried)
+            if constexpr (!RUN_FIRST) mfma_step(ca, cw, std::integral_constant<int, OBP>{});       // the previous stage's second step (fragments carried)
             h2c_frags_landed<NB>(fa, fw);
             LVAE_FENCE();
             // second k16 step -> the carried registers (their last readers, the MFMAs above, have been issued)
@@ -297,11 +312,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                 H2C_DSR(cw[b][1], wq + po[3], b * 4096);
             }
             LVAE_FENCE();
-            mfma_step(fa, fw);
+            mfma_step(fa, fw, std::integral_constant<int, OB>{});
             if constexpr (RUN_LAST) {
                 h2c_frags_landed<NB>(ca, cw);
                 LVAE_FENCE();
-                mfma_step(ca, cw);
+                mfma_step(ca, cw, std::integral_constant<int, OB>{});
             }
             static_assert(S::NI_F <= 6 && S::NI_G <= 6, "DMA instructions of a stage must fit behind the MFMA groups of two k16 steps");
 #pragma unroll
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #ifdef H2C_EXP_NOEPI
                             rv[g][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #else
-                            rv[g][b] = *(const f32x4*)(d.res + rbg + wn * (C / 2) + 32 * b + (lio & ~3));
+                            rv[g][b] = *(const f32x4*)(d.res + rbg + col_of(b) + (lio & ~3));
 #endif
                     }
                 }
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #endif
                         f32x4 o = {oH[b][4 * g + 0], oH[b][4 * g + 1], oH[b][4 * g + 2], oH[b][4 * g + 3]};
                         o[0] += rv[g][b][0]; o[1] += rv[g][b][1]; o[2] += rv[g][b][2]; o[3] += rv[g][b][3];
-                        *(f32x4*)(d.out + rbg + wn * (C / 2) + 32 * b + (lio & ~3)) = o;
+                        *(f32x4*)(d.out + rbg + col_of(b) + (lio & ~3)) = o;
                     }
                 }
             }
@@ -411,11 +426,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #endif
 }
 
-template <int C_, int HID_, int HC_>
+template <int C_, int HID_, int HC_, int BM_ = 128, int NSUB_ = 1, int NBUF_ = 3>
 int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
-    using S = H2C<C_, HID_, HC_>;
+    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_>;
     static LdsAttr attr;
-    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_>, S::LDS)) return ae;
+    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_>, S::LDS)) return ae;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -426,7 +441,7 @@ int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
     if ((long)d->M * S::C * 4 > 0x7fffffffL) return -22;    // 32-bit row offsets in the epilogue, one buffer descriptor per tile base
     const int n_tiles = (d->M + S::BM - 1) / S::BM;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;      // one persistent workgroup per CU (it owns the whole LDS)
-    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_, HC_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
+    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -437,5 +452,6 @@ extern "C" int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream) {
     if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || d->M <= 0) return -22;
     if (d->C == 192 && d->hid == 384) return launch_h2c<192, 384, 128>(d, (hipStream_t)stream);
     if (d->C == 128 && d->hid == 192) return launch_h2c<128, 192, 64>(d, (hipStream_t)stream);
+    if (d->C == 384 && d->hid == 768) return launch_h2c<384, 768, 128, 64, 3, 4>(d, (hipStream_t)stream);
     return -22;
 }

@@ -383,12 +383,18 @@ class Plan:
 
     # (C, hidden) block shapes whose MLP runs as ONE launch (csrc/mlp_h2c.hip: hidden dimension walked in chunks, weights streamed): the
     # decoder's and the encoder's stride-4 blocks
-    FUSED_MLP_SHAPES = ((128, 192), (192, 384))
+    FUSED_MLP_SHAPES = ((128, 192), (192, 384), (384, 768))
+    # (384, 768) -- 64-row tiles, LDS-bound: profiles/r04_mlp_h2c_384x768.txt -- pays from three tiles per CU on (-9 ... -13 %) and loses
+    # at the 1.5 (M = 24576: one pipeline group of four 512x768 images) it is never given
+    FUSED_MLP_MIN_ROWS = {(384, 768): 49152}
 
-    def mlp_fused_ok(self, C, hid, k, n_affine=1):
-        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2c.hip)?  A rule in the block's shape only; its bits
-        are the two-launch path's (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms)."""
-        return (C, hid) in self.FUSED_MLP_SHAPES and self.mlp_h2p_ok(C, hid, k, n_affine, None)
+    def mlp_fused_ok(self, C, hid, k, n_affine=1, M=None):
+        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2c.hip)?  Its bits are the two-launch path's
+        (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms), so the rule may look at the launch's
+        row count M as well as at the block's shape."""
+        if (C, hid) not in self.FUSED_MLP_SHAPES or not self.mlp_h2p_ok(C, hid, k, n_affine, None):
+            return False
+        return (M or 0) >= self.FUSED_MLP_MIN_ROWS.get((C, hid), 0)
 
     def mlp_fused(self, *, y, M, C, hid, w1, b1, w2, b2, gamma, res, out, label='mlp'):
         """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2): lvae_mlp_h2f."""

@@ -367,16 +367,19 @@ def test_gemm_h2p_serial_split_k_equals_parallel_split_k(M, N, K, S, epi):
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
 
+@pytest.mark.parametrize('C,HID', [(192, 384), (384, 768)])
 @pytest.mark.parametrize('M', [128, 1000, 300 * 128 + 5, 98304, 196608])
-def test_mlp_h2c_equals_two_gemms(M):
-    """The hidden-chunked fused MLP of the C = 192 / hidden = 384 blocks (csrc/mlp_h2c.hip: a persistent workgroup per CU walks the hidden
+def test_mlp_h2c_equals_two_gemms(M, C, HID):
+    """The hidden-chunked fused MLP of the C = 192 / hidden = 384 blocks and -- 64-row tiles, the W2 rows of a k32 step in three parts --
+    of the C = 384 / hidden = 768 blocks (csrc/mlp_h2c.hip: a persistent workgroup per CU walks the hidden
     dimension in chunks of 128 -- fc1 stages, GELU / split into LDS, fc2 stages -- with every operand streamed by LDS-DMA through one flat
     ring) against the two pre-split GEMM launches it replaces: every output bit equal.  M = 128: one tile; 1000 / 38405: ragged last
     tile, fewer tiles than CUs / more than one tile per workgroup; 98304 / 196608: the model's launches (384 / 768 tiles: several tiles
     per persistent workgroup, the ring running across tile boundaries).  In place (out aliasing the residual) like the plans use it."""
     from lvae import _native
     from lvae.models.base import pack_f16x2_k32
-    C, HID = 192, 384
+    if C == 384 and M == 196608:
+        M = 49152 + 64 * 7 + 3                                         # the stride-8 map of the model, plus a ragged tail of 64-row tiles
     g = torch.Generator().manual_seed(M)
     yf = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
     yf[3] = 0.0

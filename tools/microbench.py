@@ -157,7 +157,7 @@ def mlpf():
     from lvae._native import MlpDesc
     from lvae.models.base import pack_f16x2_k32
     C, HID = (int(v) for v in os.environ.get('LVAE_MLP_SHAPE', '128,192').split(','))
-    for M in (196608, 98304, 49152, 24576):
+    for M in (int(v) for v in os.environ.get('LVAE_MLP_MS', '196608,98304,49152,24576').split(',')):
         yf = torch.randn(M, C, device='cuda')
         W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
         b1, b2, gamma = torch.randn(HID, device='cuda'), torch.randn(C, device='cuda'), torch.rand(C, device='cuda')
