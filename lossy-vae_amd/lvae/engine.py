@@ -384,8 +384,8 @@ class Plan:
     # (C, hidden) block shapes whose MLP runs as ONE launch (csrc/mlp_h2c.hip: hidden dimension walked in chunks, weights streamed): the
     # decoder's and the encoder's stride-4 blocks
     FUSED_MLP_SHAPES = ((128, 192), (192, 384), (384, 768))
-    # (384, 768) -- 64-row tiles, LDS-bound: profiles/r04_mlp_h2c_384x768.txt -- pays from three tiles per CU on (-9 ... -13 %) and loses
-    # at the 1.5 (M = 24576: one pipeline group of four 512x768 images) it is never given
+    # (384, 768) -- 64-row tiles: profiles/r04_mlp_h2c_384x768.txt -- pays from three tiles per CU on (-9 ... -13 %) and loses at 1.5 tiles
+    # per CU (M = 24576: one pipeline group of four 512x768 images), where it is not taken
     FUSED_MLP_MIN_ROWS = {(384, 768): 49152}
 
     def mlp_fused_ok(self, C, hid, k, n_affine=1, M=None):
