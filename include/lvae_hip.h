@@ -59,6 +59,11 @@ long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t* idx, size_
                                    const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
                                    const int32_t* offset, uint8_t* out, size_t out_cap);
 
+/* Test hook of the encoder's division-free step: lvae_rans_encode_with_indexes computes x' = ((x / freq) << 16) + (x % freq) + start with
+ * a per-symbol reciprocal (Alverson; the form of ryg's rans64.h -- the published coder divides).  This applies ONE encode step to the
+ * state x both ways (division / reciprocal) and returns both next states; 0 if the renormalisation decisions agree too.  1 <= freq <= 65535. */
+int lvae_rans_enc_step_selftest(uint64_t x, uint32_t start, uint32_t freq, uint64_t* by_division, uint64_t* by_reciprocal);
+
 /* Replaces RansDecoder().decode_with_indexes(bytes, indexes, cdfs, cdf_sizes, offsets) -> list[int]
  * (qarv/model.py:113 via GaussianConditional.decompress).  Returns 0 or <0 (-1 malformed, -3 overrun). */
 int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,

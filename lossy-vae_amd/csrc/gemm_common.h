@@ -40,6 +40,22 @@ struct LdsAttr {
     }
 };
 
+// Compute units of the CURRENT device, cached per device ordinal (a process may drive several GPUs, and the pipeline-group threads may
+// ask at the same time: relaxed atomics, every writer stores the same value).  Persistent kernels size their grid by it -- one
+// workgroup per CU that owns the whole LDS -- so a count taken from another device would break their residency assumption.
+inline int lvae_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::atomic<int>& c = cached[dev & 63];
+    int n = c.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+    c.store(v, std::memory_order_relaxed);
+    return v;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));

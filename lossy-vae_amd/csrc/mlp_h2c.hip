@@ -431,13 +431,7 @@ int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
     using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_>;
     static LdsAttr attr;
     if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_>, S::LDS)) return ae;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = lvae_cu_count();                       // per device (gemm_common.h), like the LDS attribute above
     if ((long)d->M * S::C * 4 > 0x7fffffffL) return -22;    // 32-bit row offsets in the epilogue, one buffer descriptor per tile base
     const int n_tiles = (d->M + S::BM - 1) / S::BM;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;      // one persistent workgroup per CU (it owns the whole LDS)

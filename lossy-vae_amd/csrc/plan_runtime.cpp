@@ -93,6 +93,13 @@ int lvae_rans_decode_batch_tabs(int n_streams, const uint8_t* const* in, const s
                                 const size_t* n, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
                                 int32_t* const* sym_out, int* status, int n_threads, LvaeDecTabs* tabs);
 
+// rans_host.cpp: a block's streams handed to the coder pool without waiting for them
+struct LvaeEncJob;
+LvaeEncJob* lvae_rans_encode_batch_begin(int n_streams, const int32_t* const* sym, const uint8_t* const* idx, const size_t* n,
+                                         const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                         uint8_t* const* out, const size_t* out_cap, long* out_len, int n_threads);
+int lvae_rans_encode_batch_end(LvaeEncJob* e);
+
 namespace {
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
@@ -143,7 +150,9 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
             // a stream that does not decode: corrupt / truncated -- or decoded against garbage scale indexes because a prior parameter was
             // non-finite (the indexes themselves are always valid table rows): the status word tells the two apart
             if (failed_block) *failed_block = b;
-            if (status_dev && status_host && hipMemcpy(status_host, status_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && *status_host != 0)
+            // (on the group's own stream: a plain hipMemcpy goes through the legacy stream and would wait for the OTHER group's work too)
+            if (status_dev && status_host && hipMemcpyAsync(status_host, status_dev, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                hipStreamSynchronize(st) == hipSuccess && *status_host != 0)
                 return -75;
             return -74;
         }
@@ -201,16 +210,21 @@ extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, in
     std::vector<const int32_t*> sym_ptr(n_images);
     std::vector<const uint8_t*> idx_ptr(n_images);
     std::vector<size_t> cnt(n_images);
+    std::vector<LvaeEncJob*> jobs(n_blocks, nullptr);
     double t_wait = 0.0, t_coder = 0.0;
-    for (int b = 0; b < n_blocks; ++b) {
+    int rc_all = 0, bad_block = -1;
+    // A block's streams go to the coder pool the moment its event has fired, and this thread turns to the NEXT block's event at once:
+    // the pool codes block b while the GPU computes block b + 1 and while block b - 1 may still be in the coder (the stride-16 blocks
+    // take longer to code than the GPU takes for the block behind them) -- only what is still uncoded when the last event fires is
+    // waited for (`seconds[2]`).
+    for (int b = 0; b < n_blocks && rc_all == 0; ++b) {
         const lvae_enc_block& k = blocks[b];
         const double tw = now_s();
         int rc = (int)hipEventSynchronize(ev[b]);
-        const double tc = now_s();
-        t_wait += tc - tw;
+        t_wait += now_s() - tw;
         // the status word behind the LAST block's segment: an out-of-range input (the reference's assert), or non-finite prior parameters /
-        // posterior means (an fp16 overflow of the f16x2 arithmetic).  The earlier blocks have been coded by now (the coder takes any
-        // int32 symbol and any scale index is a valid table row, so garbage cannot hurt it); the caller discards every string
+        // posterior means (an fp16 overflow of the f16x2 arithmetic).  The earlier blocks are with the coder by now (it takes any int32
+        // symbol and any scale index is a valid table row, so garbage cannot hurt it); the caller discards every string
         if (rc == 0 && b == n_blocks - 1 && status_dev && status_host && *status_host != 0) rc = (*status_host & LVAE_STATUS_RANGE) ? -34 : -75;
         if (rc == 0) {
             for (int i = 0; i < n_images; ++i) {
@@ -218,16 +232,24 @@ extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, in
                 idx_ptr[i] = k.idx_host + (size_t)i * k.per_image;
                 cnt[i] = k.per_image;
             }
-            rc = lvae_rans_encode_batch(n_images, sym_ptr.data(), idx_ptr.data(), cnt.data(), qcdf, row_stride, cdf_len, offset,
-                                        out + (size_t)b * n_images, out_cap + (size_t)b * n_images, out_len + (size_t)b * n_images, n_threads);
+            jobs[b] = lvae_rans_encode_batch_begin(n_images, sym_ptr.data(), idx_ptr.data(), cnt.data(), qcdf, row_stride, cdf_len, offset,
+                                                   out + (size_t)b * n_images, out_cap + (size_t)b * n_images, out_len + (size_t)b * n_images, n_threads);
+            if (!jobs[b]) rc = -12;
         }
-        t_coder += now_s() - tc;
-        if (rc != 0) {
-            if (failed_block) *failed_block = b;
-            (void)hipStreamSynchronize(st);
-            cleanup();
-            return rc;
-        }
+        if (rc != 0) { rc_all = rc; bad_block = b; }
+    }
+    const double tc = now_s();
+    for (int b = 0; b < n_blocks; ++b) {                      // every job that was begun is ended (it owns heap state), error or not
+        if (!jobs[b]) continue;
+        const int rc = lvae_rans_encode_batch_end(jobs[b]);
+        if (rc != 0 && rc_all == 0) { rc_all = rc; bad_block = b; }
+    }
+    t_coder = now_s() - tc;
+    if (rc_all != 0) {
+        if (failed_block) *failed_block = bad_block;
+        (void)hipStreamSynchronize(st);
+        cleanup();
+        return rc_all;
     }
     cleanup();
     if (seconds) { seconds[0] = t1 - t0; seconds[1] = t_wait; seconds[2] = t_coder; }

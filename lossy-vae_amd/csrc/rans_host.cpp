@@ -134,6 +134,63 @@ extern "C" int lvae_build_gaussian_tables(const float* scale_table, int n_scales
     return max_len + 2;
 }
 
+// Encoder symbol entries.  rANS's encode step is x' = ((x / freq) << 16) + (x % freq) + start: a 64-bit division (25-40 cycles of
+// latency on the host cores) in the serial dependency chain of EVERY symbol -- 7.8 ns per symbol against the decoder's 2.4
+// (tools/rans_bench.py), and the encoder's backlog is what the GPU's last latent block waits behind.  The quotient
+// comes from a reciprocal instead (Alverson, "Integer division using reciprocals"; the form of ryg's rans64.h): with
+// l = ceil(log2 freq) and m = ceil(2^(63 + l) / freq), floor(x / freq) == mulhi64(x, m) >> (l - 1) for every x < 2^63 (the coder's
+// state is < 2^47 * freq <= 2^63 after the renormalisation check), and x' = x + start + q * (65536 - freq).  freq == 1 has no
+// reciprocal below 1: m = 2^64 - 1, shift 0 gives x - 1 for x >= 1, compensated in the bias.  An entry is built the first time a
+// stream meets its (row, value) -- two divisions, ~10 ns, a few hundred to a few thousand distinct pairs per stream -- in tables
+// that live for ONE call: no shared state, the C ABI stays as it was.  Same bytes as the division form
+// (tests/test_host_coder.py::test_reciprocal_encoder_equals_division_form, and every stream test against oracle/rans_oracle.c).
+namespace {
+struct EncEnt { uint64_t rcp; uint32_t bias; uint16_t freq; uint8_t shift; uint8_t ready; };      // 16 bytes
+struct EncRow {
+    int32_t offset = 0, max_value = 0;
+    EncEnt e[258];                                       // values 0 .. max_value (the escape symbol is entry max_value)
+};
+inline void enc_ent_init(EncEnt& s, uint32_t start, uint32_t freq) {
+    s.freq = (uint16_t)freq;                             // 1 <= freq <= 65535: a row has at least two symbols of frequency >= 1
+    s.ready = 1;
+    if (freq < 2) {
+        s.rcp = ~0ull; s.shift = 0; s.bias = start + (1u << kPrecision) - 1;
+    } else {
+        uint32_t shift = 0;
+        while (freq > (1u << shift)) ++shift;
+        // ((uint128)1 << (shift + 63)) + freq - 1) / freq by long division in 64-bit words
+        uint64_t x0 = freq - 1;
+        const uint64_t x1 = 1ull << (shift + 31);
+        const uint64_t t1 = x1 / freq;
+        x0 += (x1 % freq) << 32;
+        const uint64_t t0 = x0 / freq;
+        s.rcp = t0 + (t1 << 32);
+        s.shift = (uint8_t)(shift - 1);
+        s.bias = start;
+    }
+}
+inline void enc_put_ent(uint64_t& x, BackWriter& w, const EncEnt& s) {
+    const uint64_t x_max = (uint64_t)s.freq << 47;       // ((kRansL >> kPrecision) << 32) * freq
+    if (x >= x_max) { w.put((uint32_t)x); x >>= 32; }
+    const uint64_t q = (uint64_t)(((unsigned __int128)x * s.rcp) >> 64) >> s.shift;
+    x = x + s.bias + q * (uint64_t)((1u << kPrecision) - s.freq);
+}
+struct EncTabs {
+    std::unique_ptr<EncRow> rows[256];
+    // -> nullptr: the row's cdf length is out of range
+    EncRow* row(int r, const int32_t* cdf_len, const int32_t* offset) {
+        if (rows[r]) return rows[r].get();
+        const int32_t mv = cdf_len[r] - 2;
+        if (mv < 1 || mv > 256) return nullptr;
+        rows[r].reset(new EncRow);
+        rows[r]->offset = offset[r];
+        rows[r]->max_value = mv;
+        for (auto& e : rows[r]->e) e.ready = 0;
+        return rows[r].get();
+    }
+};
+}  // namespace
+
 extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t* idx, size_t n,
                                               const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
                                               const int32_t* offset, uint8_t* out, size_t out_cap) {
@@ -143,14 +200,28 @@ extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t*
     const size_t cap_words = (out_cap - (size_t)(aligned - out)) / 4;
     BackWriter w{(uint32_t*)aligned, (uint32_t*)aligned + cap_words};
     uint64_t x = kRansL;
+    std::unique_ptr<EncTabs> T(new (std::nothrow) EncTabs);
+    if (!T) return -12;
+    EncRow* cur = nullptr;
+    int32_t cur_row = -1;
     for (size_t ii = n; ii-- > 0;) {
         const int32_t row_i = idx[ii];
-        const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
-        const int32_t max_value = cdf_len[row_i] - 2;
-        if (max_value < 1) return -4;
-        int32_t value = sym[ii] - offset[row_i];
-        if (value >= 0 && value < max_value) {
-            enc_put(x, w, (uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]));
+        if (row_i != cur_row) {
+            cur = T->row(row_i, cdf_len, offset);
+            if (!cur) return -4;
+            cur_row = row_i;
+        }
+        const int32_t max_value = cur->max_value;
+        const int32_t value = sym[ii] - cur->offset;
+        const bool in_range = value >= 0 && value < max_value;
+        EncEnt& e = cur->e[in_range ? value : max_value];
+        if (__builtin_expect(!e.ready, 0)) {
+            const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
+            const int32_t v = in_range ? value : max_value;
+            enc_ent_init(e, (uint32_t)cdf[v], (uint32_t)(cdf[v + 1] - cdf[v]));
+        }
+        if (__builtin_expect(in_range, 1)) {
+            enc_put_ent(x, w, e);
             continue;
         }
         uint32_t raw;
@@ -163,7 +234,7 @@ extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t*
         const int32_t n15 = n_bypass / kMaxBypassVal, rem = n_bypass % kMaxBypassVal;
         enc_put_bits(x, w, (uint32_t)rem);
         for (int32_t j = 0; j < n15; ++j) enc_put_bits(x, w, (uint32_t)kMaxBypassVal);
-        enc_put(x, w, (uint32_t)cdf[max_value], (uint32_t)(cdf[max_value + 1] - cdf[max_value]));
+        enc_put_ent(x, w, e);
     }
     w.put((uint32_t)(x >> 32));
     w.put((uint32_t)x);
@@ -171,6 +242,20 @@ extern "C" long lvae_rans_encode_with_indexes(const int32_t* sym, const uint8_t*
     const size_t nbytes = (size_t)(((uint32_t*)aligned + cap_words) - w.ptr) * 4;
     std::memmove(out, w.ptr, nbytes);
     return (long)nbytes;
+}
+
+// the division form of the encode step (the formula as published; tests compare the reciprocal form above with it, state by state)
+extern "C" int lvae_rans_enc_step_selftest(uint64_t x, uint32_t start, uint32_t freq, uint64_t* by_division, uint64_t* by_reciprocal) {
+    if (freq < 1 || freq > 65535 || !by_division || !by_reciprocal) return -22;
+    uint32_t sink[4];
+    BackWriter w1{sink, sink + 4}, w2{sink, sink + 4};
+    uint64_t a = x, b = x;
+    enc_put(a, w1, start, freq);
+    EncEnt e;
+    enc_ent_init(e, start, freq);
+    enc_put_ent(b, w2, e);
+    *by_division = a; *by_reciprocal = b;
+    return (w1.ptr == w2.ptr) ? 0 : 1;
 }
 
 // Per-row decode tables, built lazily for the rows a stream touches (1.25 KB per row):
@@ -409,6 +494,64 @@ extern "C" int lvae_rans_encode_batch(int n_streams, const int32_t* const* sym, 
     });
     int rc = 0;
     for (int s = 0; s < n_streams; ++s) if (out_len[s] < 0) rc = (int)out_len[s];
+    return rc;
+}
+
+// Non-blocking form of lvae_rans_encode_batch for lvae_encode_blocks (plan_runtime.cpp): `begin` hands the block's streams to the pool
+// and returns at once -- the caller goes on to wait for the NEXT latent block's event, so a block whose coding takes longer than the
+// GPU needs for the following block (the stride-16 blocks: 147 456 symbols per image) no longer delays the blocks behind it -- `end`
+// takes part in whatever is left, waits, and returns the batch's status.  The pointer arrays are copied; the buffers they point to
+// must stay valid until `end`.
+struct LvaeEncJob {
+    std::vector<const int32_t*> sym;
+    std::vector<const uint8_t*> idx;
+    std::vector<size_t> n, out_cap;
+    std::vector<uint8_t*> out;
+    long* out_len = nullptr;
+    const int32_t *qcdf = nullptr, *cdf_len = nullptr, *offset = nullptr;
+    int row_stride = 0;
+    std::shared_ptr<Job> job;
+    void run(int s) {
+        out_len[s] = lvae_rans_encode_with_indexes(sym[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, out[s], out_cap[s]);
+    }
+};
+LvaeEncJob* lvae_rans_encode_batch_begin(int n_streams, const int32_t* const* sym, const uint8_t* const* idx, const size_t* n,
+                                         const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                         uint8_t* const* out, const size_t* out_cap, long* out_len, int n_threads) {
+    if (n_streams < 0) return nullptr;
+    LvaeEncJob* e = new (std::nothrow) LvaeEncJob;
+    if (!e) return nullptr;
+    e->sym.assign(sym, sym + n_streams); e->idx.assign(idx, idx + n_streams); e->n.assign(n, n + n_streams);
+    e->out.assign(out, out + n_streams); e->out_cap.assign(out_cap, out_cap + n_streams);
+    e->out_len = out_len; e->qcdf = qcdf; e->cdf_len = cdf_len; e->offset = offset; e->row_stride = row_stride;
+    for (int s = 0; s < n_streams; ++s) out_len[s] = 0;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 1) {                                 // one thread: coded here and now, like lvae_rans_encode_batch
+        for (int s = 0; s < n_streams; ++s) e->run(s);
+    } else if (n_streams > 0) {
+        auto j = std::make_shared<Job>();
+        j->n = n_streams;
+        j->max_workers = n_threads < n_streams ? n_threads : n_streams;
+        j->ctx = (void*)e;
+        j->run = [](void* c, int i) { ((LvaeEncJob*)c)->run(i); };
+        e->job = j;
+        Pool::get().submit(j);
+    }
+    return e;
+}
+int lvae_rans_encode_batch_end(LvaeEncJob* e) {
+    if (!e) return -12;
+    const int n = (int)e->sym.size();
+    if (e->job) {
+        Job& j = *e->job;
+        Pool::work(j);
+        for (int it = 0; it < 20000 && j.done.load(std::memory_order_acquire) < n; ++it) cpu_relax();
+        std::unique_lock<std::mutex> l(j.m);
+        j.cv.wait(l, [&] { return j.done.load() >= n; });
+    }
+    int rc = 0;
+    for (int s = 0; s < n; ++s) if (e->out_len[s] < 0) rc = (int)e->out_len[s];
+    delete e;
     return rc;
 }
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     'lvae_build_gaussian_tables': (_i, [_vp, _i, _d, _i, _vp, _i, _vp, _vp]),
     'lvae_rans_encode_with_indexes': (_l, [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _sz]),
     'lvae_rans_decode_with_indexes': (_i, [_vp, _sz, _vp, _sz, _vp, _i, _vp, _vp, _vp]),
+    'lvae_rans_enc_step_selftest': (_i, [C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp]),
     'lvae_rans_encode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     'lvae_rans_decode_batch': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     'lvae_gemm_f32': (_i, [C.POINTER(GemmDesc), _vp]),

@@ -388,25 +388,41 @@ class Plan:
     # per CU (M = 24576: one pipeline group of four 512x768 images), where it is not taken
     FUSED_MLP_MIN_ROWS = {(384, 768): 49152}
 
-    def mlp_fused_ok(self, C, hid, k, n_affine=1, M=None):
-        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2c.hip)?  Its bits are the two-launch path's
-        (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms), so the rule may look at the launch's
-        row count M as well as at the block's shape."""
+    def mlp_fused_ok(self, C, hid, k, n_affine=1, M=None, rows_per_image=None):
+        """f16x2 plans: does the block's MLP run as ONE launch (csrc/mlp_h2c.hip)?  Its bits are those of the two-launch path WITHOUT
+        split-K (tests/test_gpu_f16x2.py::test_mlp_h2f_equals_two_gemms, test_mlp_h2c_equals_two_gemms).  Shapes without a row threshold
+        are fused at every size -- a rule in the block's shape alone.  A shape WITH a threshold (FUSED_MLP_MIN_ROWS) looks at the
+        launch's row count M = B * rows_per_image, so batched and single-image plans of one image size may differ in their choice:
+        that is only sound where the two-launch alternative is the S = 1 pipeline too, i.e. on maps of >= H2P_MIN_ROWS_PER_IMAGE rows per
+        image (mlp_h2p_ok with rows_per_image) -- on smaller maps the alternative is split-K with another summation order, and the
+        fused form is not taken whatever the batch (qres34m's width-384 blocks on 256x256 images in groups of >= 48).
+        (Launches beyond the kernel's 32-bit row offsets, M * C * 4 >= 2^31, are cut into row ranges by mlp_fused -- rows are independent.)"""
         if (C, hid) not in self.FUSED_MLP_SHAPES or not self.mlp_h2p_ok(C, hid, k, n_affine, None):
             return False
-        return (M or 0) >= self.FUSED_MLP_MIN_ROWS.get((C, hid), 0)
+        min_rows = self.FUSED_MLP_MIN_ROWS.get((C, hid), 0)
+        if min_rows == 0:
+            return True
+        if rows_per_image is None or not self.mlp_h2p_ok(C, hid, k, n_affine, rows_per_image):
+            return False
+        return (M or 0) >= min_rows
 
     def mlp_fused(self, *, y, M, C, hid, w1, b1, w2, b2, gamma, res, out, label='mlp'):
-        """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2): lvae_mlp_h2f."""
-        assert self.prec == 4 and (C, hid) in self.FUSED_MLP_SHAPES and M * C * 4 < 2 ** 31
+        """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2): lvae_mlp_h2f.  The kernel addresses a
+        launch's rows with 32-bit byte offsets: a map of 2 GiB or more goes out as several launches over row ranges (the MLP's rows are
+        independent, so the bits do not change -- ADVICE r04)."""
+        assert self.prec == 4 and (C, hid) in self.FUSED_MLP_SHAPES
         w1h, w2h = self.w16_k32.get(w1), self.w16_k32.get(w2)
         assert w1h and w2h, f'{label}: weights do not fit the pre-split operand format'
-        d = _native.MlpDesc()
-        d.y, d.w1, d.b1, d.w2, d.b2, d.gamma, d.res, d.out = y, w1h, b1, w2h, b2, gamma, res, out
-        d.M, d.C, d.hid = M, C, hid
-        self.keep.append(d)
+        max_rows = ((2 ** 31 - 1) // (C * 4)) // 128 * 128
+        for r0 in range(0, M, max_rows):
+            rows = min(max_rows, M - r0)
+            d = _native.MlpDesc()
+            o = r0 * C * 4                                   # y (H2K32 planes), res and out all have C * 4 bytes per row
+            d.y, d.w1, d.b1, d.w2, d.b2, d.gamma, d.res, d.out = y + o, w1h, b1, w2h, b2, gamma, res + o, out + o
+            d.M, d.C, d.hid = rows, C, hid
+            self.keep.append(d)
+            self.add(self.lib.lvae_mlp_h2f, (ctypes.byref(d),), label if M <= max_rows else f'{label}[{r0}:]')
         self.flops += 4 * M * C * hid
-        self.add(self.lib.lvae_mlp_h2f, (ctypes.byref(d),), label)
 
     # ---- execution
     # opt-in: measured +-0.5% at B=1 (the path is GPU-latency-bound, not launch-bound) and HIP's global capture mode

@@ -9,6 +9,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ..engine import NonFiniteError
+
 
 import threading
 _W16_LOCK = threading.Lock()
@@ -285,12 +287,16 @@ class CodecBase(nn.Module):
                                                   ctypes.cast(tail, ctypes.c_void_p) if n_tail else None, n_tail, st_dev, pl.status_host.data_ptr(),
                                                   ctypes.c_void_p(stream.cuda_stream),
                                                   ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
-        if rc == -75:           # a stream that did not decode because its scale indexes came from NaN / inf prior parameters
-            stream.synchronize()
-            pl.raise_if_flagged(int(pl.status_host[0]), where=f'while decoding (latent block {fb.value} of {nb})')
-        if rc == -74:
-            raise ValueError(f'rANS decode failed in latent block {fb.value} (corrupt or truncated bitstream)')
         if rc != 0:
+            # every error exit leaves the plan's status word CLEAN: a bit that stayed set on the device (a corrupt stream decoded against
+            # garbage, a failed launch) would otherwise fail the next, healthy call on this cached plan
+            stream.synchronize()
+            word = int(pl.status_host[0]) if rc == -75 else 0
+            self._reset_status(pl)
+            if rc == -75:       # a stream that did not decode because its scale indexes came from NaN / inf prior parameters
+                raise NonFiniteError(word, getattr(pl, 'prec_name', None), f'while decoding (latent block {fb.value} of {nb})')
+            if rc == -74:
+                raise ValueError(f'rANS decode failed in latent block {fb.value} (corrupt or truncated bitstream)')
             raise RuntimeError(f'native decode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
         if T is not None:
             T['dec_gpu_seg'] = T.get('dec_gpu_seg', 0) + secs[0]
@@ -318,15 +324,27 @@ class CodecBase(nn.Module):
                                                   st_dev, pl.status_host.data_ptr(), ctypes.c_void_p(stream.cuda_stream),
                                                   ctypes.c_void_p(ss) if ss is not None else None, int(nthreads), ctypes.byref(fb), ctypes.byref(fo), secs)
         if rc in (-34, -75):    # out-of-range input (the reference's assert) / NaN or inf in a prior parameter or posterior mean
-            pl.raise_if_flagged(int(pl.status_host[0]), where='while encoding')
+            word = int(pl.status_host[0])
+            self._reset_status(pl)
+            pl.raise_if_flagged(word, where='while encoding')
             raise RuntimeError(f'native encode reported rc={rc} without a status word')
         if rc != 0:
+            self._reset_status(pl)
             raise RuntimeError(f'native encode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
         if T is not None:
             T['enc_launch'] = T.get('enc_launch', 0) + secs[0]
             T['enc_gpu_wait'] = T.get('enc_gpu_wait', 0) + secs[1]
             T['enc_rans'] = T.get('enc_rans', 0) + secs[2]
         return [[outs[li * n + b][:out_len[li * n + b]].tobytes() for b in range(n)] for li in range(nb)]
+
+    @staticmethod
+    def _reset_status(pl):
+        """Error exits of the native group loops: wait for the plan's device, then zero its status word and the pinned mirror."""
+        if getattr(pl, 'status', None) is not None:
+            torch.cuda.synchronize(pl.device)
+            pl.status.zero_()
+            pl.status_host.zero_()
+            torch.cuda.synchronize(pl.device)
 
     def _check_decoded(self, groups, plan_of):
         """decompress_batch's last step: every group's decode has been queued (its status word travels to pinned memory behind its

@@ -245,7 +245,7 @@ class _NetPlan(Plan):
         # planes, 4 bytes per element like fp32) and the two GEMMs stream both operands by LDS-DMA with no conversion in the main loop
         # (reduced-precision plans: the same idea with MX-fp8 -- the producers quantise, csrc/gemm_q8.hip streams)
         # (small maps: the split-K layers -- pre-split + serial split-K where the batch makes that the faster form, same bits: engine.mlp_pipeline)
-        if self.mlp_fused_ok(C, hid, k, M=M):
+        if self.mlp_fused_ok(C, hid, k, M=M, rows_per_image=H * W):
             # C = 128 / hidden = 192 (the decoder's stride-4 blocks): fc1 -> GELU -> fc2 as one launch, the hidden tile never leaves the CU
             self.add(lib.lvae_dwconv_ln_h2, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off), ptr(pk.adaln, off + C),
                                              y.data_ptr(), self.B, H, W, C, k), p + '.dwln')

@@ -403,7 +403,7 @@ class _QresPlan(Plan):
         pk, lib = self.pk, self.lib
         C, k, hid = m.dim, m.kernel_size, m.hidden
         M = self.B * H * W
-        if self.mlp_fused_ok(C, hid, k, M=M):
+        if self.mlp_fused_ok(C, hid, k, M=M, rows_per_image=H * W):
             # C = 192 / hidden = 384 (the stride-4 blocks of qres34m, encoder and decoder): fc1 -> GELU -> fc2 as one launch (csrc/mlp_h2c.hip),
             # the bits of the two launches below
             y = self.buf('y', M * C)

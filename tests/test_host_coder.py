@@ -210,3 +210,32 @@ def test_scale_tables_are_host_independent_and_equal_the_reference(golden_dir):
         assert np.array_equal(fn(0.11, 20.0, 64).numpy(), np.load(os.path.join(golden_dir, 'discretized_gaussian_tables.npz'))['scale_table'])
         assert np.array_equal(fn(0.1, 20, 64).numpy(), np.load(os.path.join(golden_dir, 'gaussian_conditional_tables.npz'))['scale_table'])
         assert np.array_equal(fn(0.11, 20, 128).numpy(), np.load(os.path.join(golden_dir, 'qres34m_lossless_64x128.npz'))['scale_table'])
+
+
+def test_reciprocal_encoder_equals_division_form(L):
+    """The encoder's division-free step (Alverson reciprocal, csrc/rans_host.cpp::enc_put_ent) against the published formula
+    x' = ((x / freq) << 16) + (x % freq) + start, state by state: every frequency 1 .. 65535 at the edges of the state range
+    [2^31, 2^47 * freq) before renormalisation and [2^31 .. 2^63) overall, plus random states.  (The stream tests above compare whole
+    streams with the oracle coder, which divides.)"""
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    g = np.random.default_rng(7)
+
+    def check(x, start, freq):
+        rc = L.lvae_rans_enc_step_selftest(ctypes.c_uint64(x), start, freq, ctypes.byref(a), ctypes.byref(b))
+        assert rc == 0 and a.value == b.value, (x, start, freq, a.value, b.value)
+        xr = x >> 32 if x >= (freq << 47) else x                                  # the published renormalisation + step
+        assert a.value == ((xr // freq) << 16) + (xr % freq) + start
+
+    freqs = list(range(1, 300)) + [2 ** k + d for k in range(8, 16) for d in (-1, 0, 1)] + [65535, 65534, 43691, 21845, 33333] + \
+        [int(v) for v in g.integers(300, 65535, size=400)]
+    for freq in freqs:
+        if not 1 <= freq <= 65535:
+            continue
+        hi = freq << 47                                                           # x_max: states at / above it are renormalised first
+        xs = [1 << 31, (1 << 31) + 1, hi - 1, hi, hi + 1, (1 << 63) - 1, (1 << 63) - freq, (1 << 62) + 12345, hi - freq, hi - freq - 1,
+              (hi // freq) * freq, (hi // freq) * freq - 1]
+        xs += [int(v) for v in g.integers(1 << 31, 1 << 63, size=40, dtype=np.uint64)]
+        xs += [int(v) % hi for v in g.integers(1 << 31, 1 << 63, size=20, dtype=np.uint64) if int(v) % hi >= (1 << 31)]
+        for x in xs:
+            if (1 << 31) <= x < (1 << 63):
+                check(x, int(g.integers(0, 65536 - freq + 1)), freq)

@@ -146,6 +146,44 @@ def test_mlp_pipeline_keeps_the_slice_count_per_image_and_picks_the_form_by_batc
     assert pl.mlp_pipeline(512, 1024, 3, 384) == (False, False, None, None)        # other arithmetics: untouched
 
 
+def test_fused_mlp_rule_never_trades_split_k_bits_for_a_batch_threshold():
+    """engine.Plan.mlp_fused_ok: a fused-MLP shape with a ROW threshold may follow the batch only where the
+    two-launch alternative has the fused kernel's summation order (maps of >= 1536 rows per image: S = 1); on smaller maps the
+    alternative is split-K, so the fused form is refused at EVERY batch size there -- qres34m's width-384 blocks on 256x256 images
+    decode the same in a group of 48 as alone.  Shapes without a threshold are fused whatever the size; an oversized launch is cut
+    into row ranges instead of changing pipeline."""
+    from lvae import _native
+    from lvae.engine import Plan
+
+    class _Lib:
+        lvae_mlp_h2f = object()
+
+    def plan(B):
+        pl = Plan.__new__(Plan)
+        pl.prec, pl.w16_k32, pl.B = 4, {1: 11, 2: 22}, B
+        pl.ops, pl.keep, pl.flops, pl.on_side, pl.lib = [], [], 0, False, _Lib()
+        return pl
+    for B in (1, 4, 8, 48, 96, 512):
+        rows = 32 * 32                                   # a 256x256 image at stride 8
+        assert not plan(B).mlp_fused_ok(384, 768, 5, M=B * rows, rows_per_image=rows), B
+        assert plan(B).mlp_pipeline(384, 768, 5, rows)[2:] == plan(1).mlp_pipeline(384, 768, 5, rows)[2:]
+        assert not plan(B).mlp_fused_ok(384, 768, 5, M=B * rows)              # no per-image row count given: never by M alone
+    assert not plan(4).mlp_fused_ok(384, 768, 7, M=4 * 6144, rows_per_image=6144)      # below the threshold: two launches, S = 1 ...
+    assert plan(8).mlp_fused_ok(384, 768, 7, M=8 * 6144, rows_per_image=6144)          # ... the same bits as the fused launch
+    assert plan(4).mlp_pipeline(384, 768, 7, 6144) == (True, True, 1, 1)
+    for B, rows in ((1, 64), (1, 24576), (8, 24576), (4000, 1024)):
+        assert plan(B).mlp_fused_ok(192, 384, 7, M=B * rows, rows_per_image=rows)
+        assert plan(B).mlp_fused_ok(128, 192, 7, M=B * rows, rows_per_image=rows)
+    pl = plan(4000)                                       # 4000 x 1024 rows x 192 channels x 4 B = 3.1 GB: two row ranges, offsets in bytes
+    M = 4000 * 1024
+    pl.mlp_fused(y=1 << 40, M=M, C=192, hid=384, w1=1, b1=5, w2=2, b2=6, gamma=7, res=2 << 40, out=3 << 40)
+    descs = [d for d in pl.keep if isinstance(d, _native.MlpDesc)]
+    assert len(descs) == 2 and sum(d.M for d in descs) == M and all(d.M * 192 * 4 < 2 ** 31 for d in descs)
+    assert descs[0].M % 128 == 0
+    assert descs[1].y - descs[0].y == descs[0].M * 192 * 4 == descs[1].out - descs[0].out == descs[1].res - descs[0].res
+    assert pl.flops == 4 * M * 192 * 384
+
+
 def test_numa_pinning_groups_ranks_by_host(monkeypatch):
     """lvae/utils/numa.pin_ranks_collectively on a faked 2-node x 4-GPU job: ranks are grouped by HOSTNAME (identical cpulists on two
     machines must not be pooled), split their node's cores in global-rank order, and refuse a topology that covers < 90 % of the CPUs."""

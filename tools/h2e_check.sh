@@ -1,4 +1,4 @@
-# Epilogue-interleaved persistent fc1 GEMM study (csrc/gemm_h2e.hip): bit-equality, then cfg 1 (product choice) against cfg 51, then the
+# Epilogue-interleaved persistent fc1 GEMM study (tools/studies/gemm_h2e.hip): bit-equality, then cfg 1 (product choice) against cfg 51, then the
 # study's ablations.  Build first (container):
 #   EXTRA_SRC=gemm_h2e.hip tools/build_exp.sh h2e gemm_h2p.hip -DLVAE_EXP_H2E
 #   for v in NOSLICE NOSTORE NOMFMA; do EXTRA_SRC=gemm_h2e.hip tools/build_exp.sh h2e_$v gemm_h2p.hip -DLVAE_EXP_H2E -DH2E_EXP_$v; done

@@ -1,4 +1,4 @@
-"""Bit-equality of the epilogue-interleaved persistent fc1 GEMM study (csrc/gemm_h2e.hip, cfg = 51) against gemm_h2p.
+"""Bit-equality of the epilogue-interleaved persistent fc1 GEMM study (tools/studies/gemm_h2e.hip, cfg = 51) against gemm_h2p.
 Needs an experimental library that links the study in:
     EXTRA_SRC=gemm_h2e.hip tools/build_exp.sh h2e gemm_h2p.hip -DLVAE_EXP_H2E;  LVAE_LIB=_bin/h2e/liblvae_hip.so python tools/h2e_equal.py
 One tile, ragged M and N (448 = 7 column tiles, 96 = 1.5), fewer tiles than workgroups, and the model's launches (several tiles per

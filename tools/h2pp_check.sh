@@ -1,5 +1,5 @@
 #!/bin/bash
-# persistent f16x2 GEMM (csrc/gemm_h2pp.hip): bit-equality tests, then the microbench shapes per tile code on one box
+# persistent f16x2 GEMM (tools/studies/gemm_h2pp.hip): bit-equality tests, then the microbench shapes per tile code on one box
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/h2pp
 timeout 900 python -m pytest tests/test_gpu_f16x2.py -q -x -k "h2p" 2>&1 | tail -5 > gpurun_out/h2pp/tests.txt
 cat gpurun_out/h2pp/tests.txt

@@ -1,4 +1,4 @@
-# persistent loader-wave GEMM (csrc/gemm_h2q.hip, cfg 61) vs gemm_h2p 128 x 64 (cfg 21) and the product choice (cfg 1)
+# persistent loader-wave GEMM (tools/studies/gemm_h2q.hip, cfg 61) vs gemm_h2p 128 x 64 (cfg 21) and the product choice (cfg 1)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/h2q
 mkdir -p $O

@@ -1,4 +1,4 @@
-"""Bit-equality of the persistent loader-wave GEMM study (csrc/gemm_h2q.hip, cfg = 61) against gemm_h2p's 128 x 64 tile (cfg = 21).
+"""Bit-equality of the persistent loader-wave GEMM study (tools/studies/gemm_h2q.hip, cfg = 61) against gemm_h2p's 128 x 64 tile (cfg = 21).
 Needs an experimental library that links the study in:
     EXTRA_SRC=gemm_h2q.hip tools/build_exp.sh h2q gemm_h2p.hip -DLVAE_EXP_H2Q;  LVAE_LIB=_bin/h2q/liblvae_hip.so python tools/h2q_equal.py
 One tile, fewer tiles than workgroups, ragged M and N, two to eighteen tiles per persistent workgroup (the ring running across tile

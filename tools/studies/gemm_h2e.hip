@@ -22,7 +22,7 @@
 // 88, its 128 x 128: 52 -- with two accumulator pairs per wave the loop is bound by LDS fill and fragment reads, and 128 x 128 per four
 // waves + eight units of epilogue state do not fit 256 registers); the interleaved slices add 32 us to it -- ten VALU instructions per
 // MFMA where six are free -- and the stores behind the tile-boundary vmcnt(0) another 35.
-#include "gemm_common.h"
+#include "../../lossy-vae_amd/csrc/gemm_common.h"
 
 #include <type_traits>
 #include <utility>

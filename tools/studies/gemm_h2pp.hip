@@ -22,7 +22,7 @@
 // therefore not built; the file stays as the record of the measurement.
 // Arithmetic per output element is gemm_h2p_kernel's (same MFMA sequence per accumulator, same epilogue expression), so every output
 // bit equals gemm_h2p_kernel's and gemm_h2_kernel's.
-#include "gemm_common.h"
+#include "../../lossy-vae_amd/csrc/gemm_common.h"
 
 #include <type_traits>
 

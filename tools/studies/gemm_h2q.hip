@@ -22,7 +22,7 @@
 // hidden map: 42 us), a CU's vector-memory pipe is one in-order queue, and while it is backed up with one workgroup's stores the other
 // workgroup's LDS-DMA loads wait behind them: main loop and store phase add up whoever issues what.  Only not writing the map helps
 // (mlp_h2c.hip).
-#include "gemm_common.h"
+#include "../../lossy-vae_amd/csrc/gemm_common.h"
 
 namespace {
 
