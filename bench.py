@@ -8,8 +8,8 @@ resident in HBM, `compress` then `decompress`, device sync after each phase, hos
 A "step" = one pass of the hot path over one batch: compress_batch(8 images) + decompress_batch(8 strings).
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      -- the dominant kernel family (the PLAIN channel-mixing GEMMs: MLP fc1/fc2 + 1x1 convs, 87% of the path's FLOPs):
-                   algorithmic FLOPs of those launches / their HIP-event-measured durations (extra single-stream steps after the
-                   timed region).  Default arithmetic f16x2: against 2500/3 = 833.3 TFLOP/s (three fp16 MFMAs per fp32-accurate
+                   algorithmic FLOPs of those launches / their HIP-event-measured durations (extra steps after the timed region on the timed
+                   region's own plans, the pipeline groups replayed one after the other).  Default arithmetic f16x2: against 2500/3 = 833.3 TFLOP/s (three fp16 MFMAs per fp32-accurate
                    product step); --precision bf16x3: 2500/6 = 416.7; --precision fp32: the 157.3 TFLOP/s fp32 MFMA peak; bf16 / fp8: HBM-bound,
                    algorithmic bytes against 8 TB/s.  `traffic` (HBM bytes per launch) cannot be read from inside this process: it
                    is copied from the committed rocprofv3 --pmc passes of the same command and labelled so (`traffic_source`);
@@ -90,14 +90,86 @@ class KernelTimer:
                     raise RuntimeError(f'{label}: rc={rc}')
                 if sel:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record(s)
-                    timer.pairs.append((e0, e1, label))
+                    timer.pairs.append((e0, e1, label, fn, args))
         return run
 
     def summary(self):
         tot = 0.0
-        for e0, e1, _ in self.pairs:
+        for e0, e1, *_ in self.pairs:
             tot += e0.elapsed_time(e1)
         return tot, len(self.pairs)
+
+
+def launch_work(fn, a):
+    """(algorithmic flop, algorithmic HBM bytes) of one recorded GEMM-family launch: a GEMM reads A and writes the result (+ the
+    residual rows) once and the weights once; a fused fc1 -> GELU -> fc2 launch (csrc/mlp_h2c.hip) counts as its two GEMMs and moves
+    y + residual + result once (4 bytes per element each) and both weight matrices -- the hidden map never leaves the CU."""
+    import ctypes
+    from lvae import _native as nat
+    if fn is nat.lib().lvae_mlp_h2f:
+        m = ctypes.cast(a[0], ctypes.POINTER(nat.MlpDesc)).contents
+        return 4.0 * m.M * m.C * m.hid, 12.0 * m.M * m.C + 8.0 * m.C * m.hid
+    d = ctypes.cast(a[0], ctypes.POINTER(nat.GemmDesc)).contents
+    ea = 2 if d.a_bf16 else 4
+    eo = 2 if d.out_bf16 else 4
+    ew = {0: 4, 1: 2, 2: 6, 3: 1, 4: 4}[d.prec]
+    return 2.0 * d.M * d.N * d.K, float(ea * d.M * d.K + ew * d.N * d.K + eo * d.M * d.N * (2 if d.epi in (2, 3) else 1))
+
+
+def executed_ops(key, pl):
+    """The launches of a plan that a step really issues: an encode stops behind the last latent block's quantize launch (the
+    reference's CompresionStopFlag, qarv/model.py:310-312), a decode runs the whole plan."""
+    return pl.ops[:pl.qcuts[-1]] if key[0].startswith('enc') and pl.qcuts else pl.ops
+
+
+def roofline_pass(model, dev, plans, n_steps, step_fn, pred):
+    """Replay `plans` -- the (key, plan) pairs the timed region ran -- for n_steps extra steps with the pipeline groups one after the
+    other (model.serial_groups) and the launches issued one by one from Python, every launch selected by pred(fn, args, label)
+    bracketed by HIP events on its own stream.  -> (ms of the selected launches, their number, their algorithmic flop, their
+    algorithmic HBM bytes, selected launches per step according to the plans)."""
+    timer = KernelTimer()
+    expected = sum(1 for k, pl in plans for fn, a, label, _s in executed_ops(k, pl) if callable(fn) and pred(fn, a, label))
+    saved = (model.native_group_loops, model.serial_groups)
+    # (the per-launch events need the plans replayed launch by launch from Python: the product path runs a group's whole
+    #  encode / decode as one native call -- lvae_encode_blocks / lvae_decode_blocks -- which has no hook per launch)
+    model.native_group_loops, model.serial_groups = False, True
+    n_plans = len(model._plans)
+    try:
+        for _, pl in plans:
+            pl.run = timer.wrap(pl, pred)
+        for _ in range(n_steps):
+            step_fn()
+        torch.cuda.synchronize(dev)
+    finally:
+        for _, pl in plans:
+            if 'run' in pl.__dict__:
+                del pl.run                                   # back to Plan.run
+        model.native_group_loops, model.serial_groups = saved
+    assert len(model._plans) == n_plans, 'the roofline pass must run the plans of the timed region, not build others'
+    ms, n = timer.summary()
+    flops = bytes_ = 0.0
+    for _e0, _e1, _label, fn, a in timer.pairs:
+        f, b = launch_work(fn, a)
+        flops += f
+        bytes_ += b
+    return ms, n, flops, bytes_, expected
+
+
+def attach_traffic(roof, precision, B, H, W):
+    """HBM bytes per launch of the family: NOT measured in this run (hardware counters cannot be read from inside the process);
+    copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command."""
+    files = {('f16x2', 8, 512, 768): ['r05_pmc_gemm_traffic.json', 'r04_pmc_gemm_traffic.json'], ('bf16x3', 8, 512, 768): ['r02_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic_v8.json'],
+             ('fp8', 4, 1216, 1216): ['r05_pmc_gemm_traffic_fp8_1216.json', 'r03_pmc_gemm_traffic_fp8_1216.json'], ('fp8', 8, 512, 768): ['r02_pmc_gemm_traffic_fp8.json']}
+    for f in files.get((precision, B, H, W), []):
+        tp = os.path.join(REPO, 'profiles', f)
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 1e6)
+            roof['traffic_source'] = (f'NOT measured in this run: bytes per launch from the committed rocprofv3 --pmc passes of this '
+                                      f"command (profiles/{f}: FETCH_SIZE x2 + WRITE_SIZE over {tj['launches']} launches "
+                                      'of this kernel family); producer outputs still resident in the 256 MiB Infinity Cache are not '
+                                      'counted by the memory-side counters')
+            return
 
 
 def physical_cores():
@@ -295,7 +367,6 @@ def main():
     for _ in range(args.warmup):
         strings, out, _ = step()
 
-    timer = KernelTimer()
     import ctypes as _ct
     from lvae import _native as _nat
 
@@ -337,37 +408,10 @@ def main():
         stats = torch.stack(gathered).mean(0)
     bpp, mse = float(stats[0]), float(stats[1])
 
-    import ctypes
-    from lvae._native import GemmDesc
-
-    def gemm_descs(plans, pred):
-        for key, pl in plans:
-            for fn, a, label, _side in pl.ops:
-                if pred(fn, a, label):
-                    yield ctypes.cast(a[0], ctypes.POINTER(GemmDesc)).contents
-
-    def alg_bytes_of(d):
-        """Algorithmic HBM bytes of one GEMM launch: A and the result (+ the residual rows) once, the weights once."""
-        ea = 2 if d.a_bf16 else 4
-        eo = 2 if d.out_bf16 else 4
-        ew = {0: 4, 1: 2, 2: 6, 3: 1, 4: 4}[d.prec]
-        return ea * d.M * d.K + ew * d.N * d.K + eo * d.M * d.N * (2 if d.epi in (2, 3) else 1)
-
-    def any_gemm(fn, a, label):
-        return fn is _nat.lib().lvae_gemm_f32
-
-    def any_plain_gemm(fn, a, label):
-        return fn is _nat.lib().lvae_gemm_f32 and dominant(fn, a, label)
-
-    # whole-step algorithmic GEMM FLOPs (every GEMM launch of the encode + decode plans of the timed configuration)
+    # whole-step algorithmic GEMM FLOPs: every GEMM / fused-MLP launch a step issues from the encode + decode plans of the timed configuration
     timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
-    step_gflop = sum(2.0 * d.M * d.N * d.K for d in gemm_descs(timed_plans, any_gemm)) / 1e9
-    from lvae._native import MlpDesc                        # + the fused fc1 -> GELU -> fc2 launches (csrc/mlp_h2c.hip): two GEMMs each
-    for _, pl in timed_plans:
-        for fn, a, label, _side in pl.ops:
-            if fn is _nat.lib().lvae_mlp_h2f:
-                m = ctypes.cast(a[0], ctypes.POINTER(MlpDesc)).contents
-                step_gflop += 4.0 * m.M * m.C * m.hid / 1e9
+    step_gflop = sum(launch_work(fn, a)[0] for k, pl in timed_plans for fn, a, _l, _s in executed_ops(k, pl)
+                     if callable(fn) and fn in (_nat.lib().lvae_gemm_f32, _nat.lib().lvae_mlp_h2f)) / 1e9
     ms_step = dt / args.steps * 1e3
     e2e_tf = step_gflop / ms_step                          # GFLOP / ms = TFLOP/s
     roofline_e2e = {
@@ -380,44 +424,21 @@ def main():
 
     roof = None
     if not args.no_kernel_timing:
-        # Roofline pass: the timed region above runs the product configuration (two pipeline groups on two HIP streams,
-        # whose kernels interleave on the GPU, so an event pair around one launch would also time the other stream's
-        # kernels).  The dominant kernel is therefore timed in `roofline_steps` EXTRA steps of the same workload on a
-        # single stream, every such launch bracketed by HIP events on that stream.
-        model.pipeline_groups = 1
-        # (the per-launch events need the plans replayed launch by launch from Python: the product path runs a group's whole
-        #  encode / decode as one native call -- lvae_encode_blocks / lvae_decode_blocks -- which has no hook per launch)
-        model.native_group_loops = False
-        step()                                           # builds the single-group plans (untimed)
-        single = [(k, pl) for k, pl in model._plans.items() if k[1] == B and k[-1] == args.precision]
-        for _, pl in single:
-            pl.run = timer.wrap(pl, dominant)
-        for _ in range(args.roofline_steps):
-            step()
-        torch.cuda.synchronize(dev)
-        for _, pl in single:
-            del pl.run                                   # back to Plan.run
-        model.native_group_loops = True
-        ms, n_launch = timer.summary()
-        from lvae._native import MlpDesc as _MlpDesc
-
-        def fused_descs(plans):
-            for _, pl in plans:
-                for fn, a, label, _side in pl.ops:
-                    if fn is _nat.lib().lvae_mlp_h2f:
-                        yield ctypes.cast(a[0], ctypes.POINTER(_MlpDesc)).contents
-        per_step = (sum(2 * d.M * d.N * d.K for d in gemm_descs(single, any_plain_gemm)) +
-                    sum(4 * m.M * m.C * m.hid for m in fused_descs(single)))
-        # fused launches: y + residual + result once (4 bytes per element each), both weight matrices once; the hidden map never leaves the CU
-        alg_bytes = (sum(alg_bytes_of(d) for d in gemm_descs(single, any_plain_gemm)) +
-                     sum(12 * m.M * m.C + 8 * m.C * m.hid for m in fused_descs(single)))
-        flops = per_step * args.roofline_steps
+        # Roofline pass: the timed region above runs the product configuration -- the pipeline groups' plans on their own HIP streams,
+        # launched concurrently from their threads, so an event pair around one launch would also time the other group's kernels.
+        # The SAME plans (same kernels, same launch mix: nothing is rebuilt and pipeline_groups is not touched) are therefore replayed
+        # in `roofline_steps` extra steps ONE GROUP AFTER THE OTHER (model.serial_groups), launch by launch, every launch of the
+        # dominant family bracketed by HIP events on the stream it is launched on.
+        ms, n_launch, flops, alg_bytes, per_step_expected = roofline_pass(model, dev, timed_plans, args.roofline_steps, step, dominant)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        gbs = alg_bytes * args.roofline_steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        common = {'traffic': None, 'traffic_source': None, 'launches': n_launch, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
+        gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        common = {'traffic': None, 'traffic_source': None, 'launches': n_launch, 'launches_per_step': n_launch // max(1, args.roofline_steps),
+                  'timed_plans_launches_per_step': per_step_expected, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
                   'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
-                  'alg_mbytes_per_launch': round(alg_bytes * args.roofline_steps / max(1, n_launch) / 1e6, 2),
-                  'measured_over': f'{args.roofline_steps} extra single-stream steps after the timed region (plans replayed launch by launch), HIP events around every such launch'}
+                  'alg_mbytes_per_launch': round(alg_bytes / max(1, n_launch) / 1e6, 2),
+                  'measured_over': f'{args.roofline_steps} extra steps after the timed region on the timed region\'s OWN plans (pipeline groups of '
+                                   f'{", ".join(str(k[1]) for k, _ in timed_plans if k[0] == "enc")} images: the groups replayed one after the other, '
+                                   'launch by launch), HIP events around every such launch on its stream'}
         if args.precision in ('bf16', 'fp8'):
             kern = {'bf16': 'gemm_bf16_kernel<Cfg<*>, 0> (PLAIN GEMM launches: operands rounded to bf16 on the bf16 MFMA, fp32 maps in HBM)',
                     'fp8': 'gemm_lp_kernel<TN, 0, *, *> (PLAIN GEMM launches of the reduced-precision mode: bf16 maps in HBM, operands '
@@ -430,7 +451,7 @@ def main():
         elif args.precision == 'f16x2':
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0           # fp16 MFMA peak = bf16 MFMA peak; 3 MFMAs per fp32-accurate product step
             roof = {'bound': 'mfma', 'kernel': 'gemm_h2p_kernel<WM, TN, NBUF> (MLP fc1 / fc2, both operands pre-split, LDS-DMA main loop) + mlp_h2c_kernel<C, hid, chunk> '
-                                               '(fc1 -> GELU -> fc2 of the stride-4 blocks as one launch: counted as its two GEMMs, 4 M C hid flop) + '
+                                               '(fc1 -> GELU -> fc2 of a block as one launch: counted as its two GEMMs, 4 M C hid flop) + '
                                                'gemm_h2_kernel<TN, *, 0> (the other PLAIN GEMM launches); v_mfma_f32_32x32x16_f16 x 3 cross terms',
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'peak_note': '2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product step (hi*hi, hi*lo, lo*hi of a 2-term '
@@ -443,20 +464,7 @@ def main():
                     'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'peak_note': '2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product step; vs the 157.3 TFLOP/s fp32 MFMA '
                                  f'peak this launch family runs at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}', **common}
-        # HBM bytes per launch of this family: NOT measured in this run (hardware counters cannot be read from inside the process);
-        # copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command
-        tfile = {('f16x2', 8, 512, 768): 'r04_pmc_gemm_traffic.json', ('bf16x3', 8, 512, 768): 'r02_pmc_gemm_traffic.json', ('fp8', 4, 1216, 1216): 'r03_pmc_gemm_traffic_fp8_1216.json',
-                 ('fp8', 8, 512, 768): 'r02_pmc_gemm_traffic_fp8.json'}.get((args.precision, B, H, W))
-        tp = os.path.join(REPO, 'profiles', tfile) if tfile else None
-        if tp and not os.path.exists(tp) and args.precision == 'bf16x3':
-            tp = os.path.join(REPO, 'profiles', 'r01_pmc_gemm_traffic_v8.json')
-        if tp and os.path.exists(tp):
-            tj = json.load(open(tp))
-            roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 1e6)
-            roof['traffic_source'] = (f'NOT measured in this run: bytes per launch from the committed rocprofv3 --pmc passes of this '
-                                      f"command (profiles/{os.path.basename(tp)}: FETCH_SIZE x2 + WRITE_SIZE over {tj['launches']} launches "
-                                      'of this kernel family); producer outputs still resident in the 256 MiB Infinity Cache are not '
-                                      'counted by the memory-side counters')
+        attach_traffic(roof, args.precision, B, H, W)
 
     fp32_mode = None
     if world == 1 and args.fp32_steps > 0 and args.precision in ('f16x2', 'bf16x3'):
@@ -577,6 +585,21 @@ def main():
                 s5, o5, tm = step5()
                 te5 += tm - ts
             dt5 = time.time() - t1
+            # the mode's dominant family against ITS roof (HBM: bf16 maps, one byte per operand element): the plans these steps ran, the
+            # groups one after the other, events around every PLAIN GEMM launch -- the same procedure as the headline's `roofline`
+            roof5 = None
+            if not args.no_kernel_timing:
+                plans5 = [(k, pl) for k, pl in model._plans.items() if k[-1] == 'fp8' and k[2:4] in ((1216, 1216), (19, 19))]
+                ms5, n5, fl5, by5, exp5 = roofline_pass(model, dev, plans5, 2, step5, dominant)
+                gbs5 = by5 / (ms5 * 1e-3) / 1e9 if ms5 > 0 else 0.0
+                roof5 = {'bound': 'hbm', 'kernel': 'gemm_q8_kernel<*> (MLP fc1 / fc2: operands quantised by their producers, LDS-DMA main loop) + gemm_lp_kernel<TN, 0, *, *> '
+                                                   '(the other PLAIN GEMM launches: bf16 maps in HBM, MX-fp8 operands for v_mfma_scale_f32_32x32x64_f8f6f4)',
+                         'achieved': round(gbs5, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs5 / 8000.0, 4),
+                         'tflops_equiv': round(fl5 / (ms5 * 1e-3) / 1e12 if ms5 > 0 else 0.0, 2), 'traffic': None, 'launches': n5,
+                         'launches_per_step': n5 // 2, 'timed_plans_launches_per_step': exp5, 'avg_launch_us': round(ms5 * 1e3 / max(1, n5), 2),
+                         'alg_mbytes_per_launch': round(by5 / max(1, n5) / 1e6, 2),
+                         'measured_over': "2 extra steps on this configuration's own plans (groups replayed one after the other, launch by launch), HIP events around every such launch"}
+                attach_traffic(roof5, 'fp8', 4, 1216, 1216)
             # the same workload under the fp32-class arithmetic of the headline: encode and decode ratios separately (the decode half is
             # bound by one image's serial rANS -- 2.3 M symbols -- whatever the GPU does: DESIGN.md 5c)
             model.set_gemm_precision(args.precision)
@@ -601,6 +624,7 @@ def main():
                        'speedup_vs_fp32_class': {'enc': round(ef / e5, 3), 'dec': round(df / d5, 3), 'enc_dec': round((ef + df) / (e5 + d5), 3)},
                        'workload': 'qarv_base batch=4 1216x1216 (1200x1200 padded) synthetic, compress_batch+decompress_batch, '
                                    "set_gemm_precision('fp8'): bf16 activation storage + MX-fp8 (e4m3 + E8M0) MFMA GEMMs; NOT a parity path",
+                       'roofline': roof5,
                        'bpp': round(float(np.mean([len(t) * 8 / (1216 * 1216) for t in s5])), 4),
                        'psnr_db': round(float(-10 * np.log10(float((o5 - ims5).square().mean()))), 3)}
             del ims5, o5

@@ -215,6 +215,10 @@ class CodecBase(nn.Module):
         self.dec_groups = int(os.environ.get('LVAE_DEC_GROUPS', '0'))
         self._streams = []
         self._pool = None
+        # measurement hook (bench.py's roofline pass): the groups of a call run ONE AFTER THE OTHER, each on its own stream, instead of
+        # concurrently from their threads -- the same plans and launches as the product configuration, but a launch bracketed by HIP
+        # events on its stream is then alone on the GPU
+        self.serial_groups = False
         # default: fp32-class accuracy on the bf16 matrix cores (same parity as the exact fp32 MFMA path, 1.2-1.5x faster)
         self._prec = DEFAULT_PRECISION
 
@@ -424,6 +428,16 @@ class CodecBase(nn.Module):
             with torch.cuda.stream(st):
                 res = [fn(0, groups[0][0], groups[0][1], st)]
             cur.wait_stream(st)
+            return res
+        if self.serial_groups:
+            cur, res = torch.cuda.current_stream(dev), []
+            for g in range(len(groups)):
+                st = self._streams[g]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    res.append(fn(g, groups[g][0], groups[g][1], st))
+                st.synchronize()
+                cur.wait_stream(st)
             return res
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor

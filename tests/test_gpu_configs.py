@@ -434,6 +434,10 @@ def test_bench_line_carries_a_measured_roofline(offline_home, tmp_path):
     r = j['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['launches'] > 100 and r['avg_launch_us'] > 5
     assert 0.05 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    # ... on the launch mix of the TIMED region: the pass replays the timed region's own plans (two groups of
+    # four images, one after the other) -- as many launches of the family per step as those plans hold, none from other plans
+    assert r['launches'] == r['launches_per_step'] * 1 == r['timed_plans_launches_per_step'], r
+    assert 'groups of 4, 4 images' in r['measured_over'], r['measured_over']
     assert abs(j['value'] - 8 * 512 * 768 / (j['ms_per_step'] * 1e3)) < 0.01 * j['value']
     assert abs(j['ms_per_step'] - j['enc_ms_per_step'] - j['dec_ms_per_step']) < 0.05 * j['ms_per_step']
 

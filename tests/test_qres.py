@@ -165,6 +165,34 @@ def test_hip_file_round_trip_and_batch(product, tmp_path):
     assert torch.equal(xb[2:3], product.decompress(objs[2]))
 
 
+@pytest.mark.gpu
+def test_large_group_of_small_images_equals_singles(product):
+    """qres34m's width-384 blocks (hidden 768) sit on maps of 32x32 ... 4x4 for a 256x256 image -- fewer than 1536
+    rows per image, i.e. split-K layers.  A pipeline group of 48 such images has M = 49152 rows at stride 8, the fused-MLP row
+    threshold of that block shape; the fused kernel has the S = 1 summation order, the single-image path the split-K one, so the rule
+    must refuse the fused form there whatever the batch: the strings of the 48-image group equal the single-image strings, and
+    the group decodes to the single-image reconstructions."""
+    m = product
+    groups = m.pipeline_groups
+    ims = torch.cat([_img(256, 256, 400 + i) for i in range(48)], 0).cuda()
+    try:
+        m.pipeline_groups = 1
+        objs = m.compress_batch(ims)
+        xb = m.decompress_batch(objs)
+    finally:
+        m.pipeline_groups = groups
+    pl = next(p for k, p in m._plans.items() if k[0] == 'enc' and k[1] == 48)
+    from lvae import _native
+    import ctypes
+    for fn, a, lab, _s in pl.ops:
+        if callable(fn) and getattr(fn, 'lvae_name', '') == 'lvae_mlp_h2f':
+            d = ctypes.cast(a[0], ctypes.POINTER(_native.MlpDesc)).contents
+            assert (d.C, d.hid) != (384, 768), lab                       # only the stride-4 blocks (192 / 384) are fused here
+    for i in (0, 17, 47):
+        assert objs[i] == m.compress(ims[i:i + 1]), i
+        assert torch.equal(xb[i:i + 1], m.decompress(objs[i])), i
+
+
 # ----------------------------------------------------------------------------------- qres34m_lossless (SURVEY.md 8(f) row 4)
 @pytest.fixture(scope='module')
 def lossless_sd():
