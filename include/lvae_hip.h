@@ -237,7 +237,9 @@ int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int
  * point (garbage indexes, not a corrupt stream).  The caller zeroes the device word again.
  * Returns 0, a launch error (failed_block = block, failed_op = index in its segment; block n_blocks = the tail), -75 (above), or -74
  * (EBADMSG) when a stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional) receive the time spent waiting for the GPU
- * segments and inside the coder. */
+ * segments and inside the coder.  Timeline (measurement): with seconds[0] = -(capacity of the array in doubles, >= 8) on entry, absolute
+ * steady-clock stamps (s) follow the two totals: per block b, seconds[2 + 4 b ..] = segment launch begins / segment + index copy issued /
+ * indexes on the host / block decoded and its symbols on their way to the device; seconds[2 + 4 n_blocks] = tail issued. */
 typedef struct {
     const lvae_op* ops; int n_ops;
     const uint8_t* idx_dev; uint8_t* idx_host;        /* n_images * per_image bytes */

@@ -121,11 +121,15 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
     if (!tabs.t) return -12;
     double t_gpu = 0.0, t_coder = 0.0;
     int bad = -1;
+    // timeline request: seconds[0] = -(capacity in doubles) on entry -> absolute steady-clock stamps behind the two totals (header)
+    const int trace_cap = (seconds && seconds[0] <= -8.0) ? (int)(-seconds[0]) : 0;
+    auto stamp = [&](int slot, double t) { if (slot < trace_cap) seconds[slot] = t; };
     for (int b = 0; b < n_blocks; ++b) {
         const lvae_dec_block& k = blocks[b];
         const double t0 = now_s();
         int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
         if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
+        const double t_issued = now_s();
         if (rc == 0) {
             // the segment is ~0.3 ms of GPU work and the coder is waiting for it: poll the stream for a bounded while (the wake-up of a
             // blocking wait is on the chain nine times per image: -0.05 ... 0.08 ms per decode, same-box), then block
@@ -163,6 +167,7 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
         }
         const double t2 = now_s();
         t_gpu += t1 - t0; t_coder += t2 - t1;
+        stamp(2 + 4 * b, t0); stamp(3 + 4 * b, t_issued); stamp(4 + 4 * b, t1); stamp(5 + 4 * b, t2);
     }
     if (n_tail > 0) {
         int rc = lvae_run_ops(tail_ops, n_tail, stream, side_stream, &bad);
@@ -175,6 +180,7 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
             return rc;
         }
     }
+    stamp(2 + 4 * n_blocks, now_s());
     if (seconds) { seconds[0] = t_gpu; seconds[1] = t_coder; }
     return 0;
 }

@@ -219,6 +219,7 @@ class CodecBase(nn.Module):
         # concurrently from their threads -- the same plans and launches as the product configuration, but a launch bracketed by HIP
         # events on its stream is then alone on the GPU
         self.serial_groups = False
+        self.dec_stagger = float(os.environ.get('LVAE_DEC_STAGGER_MS', '0')) * 1e-3     # EXPERIMENT (r5): group g starts its decode g * stagger late
         # default: fp32-class accuracy on the bf16 matrix cores (same parity as the exact fp32 MFMA path, 1.2-1.5x faster)
         self._prec = DEFAULT_PRECISION
 
@@ -269,21 +270,48 @@ class CodecBase(nn.Module):
                 b.sym_dev, b.sym_host = pl.sym_all.data_ptr() + 4 * o, pl.sym_host.data_ptr() + 4 * o
                 lo = cut
             tail, n_tail = pl._segment(lo, len(pl.ops)) if kind == 'dec' else (None, 0)
-            cached = (arr, segs, tail, n_tail)
+            early = None
+            if kind == 'dec' and len(cuts):                # the same blocks with block 0's launches taken out: _decode_group_native issues
+                early = (cls * len(cuts))()                # that segment itself, before it looks at the strings
+                ctypes.memmove(early, arr, ctypes.sizeof(arr))
+                early[0].n_ops = 0
+            cached = (arr, segs, tail, n_tail, early)
             setattr(pl, key, cached)
         return cached
 
     def _decode_group_native(self, pl, cuts, offs, n, strings, tables, nthreads, stream, T=None):
         """strings[b][li]: image b's stream of latent block li.  Runs the group's whole decode; the caller copies pl.out afterwards."""
         from .. import _native
-        arr, _segs, tail, n_tail = self._group_blocks(pl, 'dec', cuts, offs, n)
+        arr, _segs, tail, n_tail, early = self._group_blocks(pl, 'dec', cuts, offs, n)
         nb = len(cuts)
+        # The first segment (bias -> ... -> prior of the top latent block) does not depend on the bitstream: it is on its way to the GPU
+        # before this thread turns to the strings (header parsing, container offsets, pointer tables: ~0.1-0.2 ms of interpreter time
+        # per group that used to precede the first launch -- tools/dec_timeline.py).  The foreign call releases the interpreter lock,
+        # so the other group's thread prepares meanwhile.
+        if early is not None:
+            with torch.cuda.device(pl.device):
+                pl._run_native(0, cuts[0], stream.cuda_stream)
+            arr = early
+        if callable(strings):
+            strings = strings()                            # [image][block] -> bytes, or (bytes-like container, offset, length): no copies
         qcdf, cdf_len, offset = tables
-        bufs = [np.frombuffer(strings[b][li], dtype=np.uint8) for li in range(nb) for b in range(n)]      # block-major
-        sp = (ctypes.c_void_p * len(bufs))(*[x.ctypes.data for x in bufs])
-        sl = (ctypes.c_size_t * len(bufs))(*[x.size for x in bufs])
+        addr, size = [], []
+        for li in range(nb):                               # block-major
+            for b in range(n):
+                s_ = strings[b][li]
+                if isinstance(s_, tuple):
+                    base, off, ln = s_
+                    assert isinstance(base, bytes)
+                    addr.append(ctypes.cast(ctypes.c_char_p(base), ctypes.c_void_p).value + off); size.append(ln)
+                else:
+                    addr.append(ctypes.cast(ctypes.c_char_p(s_), ctypes.c_void_p).value if len(s_) else None); size.append(len(s_))
+        sp = (ctypes.c_void_p * len(addr))(*addr)
+        sl = (ctypes.c_size_t * len(size))(*size)
         fb, fo = ctypes.c_int(-1), ctypes.c_int(-1)
-        secs = (ctypes.c_double * 2)()
+        trace = getattr(self, 'dec_trace', None)             # measurement hook (tools/dec_timeline.py): a list collects per-block stamps
+        secs = (ctypes.c_double * (64 if trace is not None else 2))()
+        if trace is not None:
+            secs[0] = -64.0
         ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
         st_dev = pl.status_ptr() if self.status_checks else None
         with torch.cuda.device(pl.device):
@@ -302,6 +330,8 @@ class CodecBase(nn.Module):
             if rc == -74:
                 raise ValueError(f'rANS decode failed in latent block {fb.value} (corrupt or truncated bitstream)')
             raise RuntimeError(f'native decode failed: rc={rc} at latent block {fb.value}, launch {fo.value}')
+        if trace is not None:
+            trace.append((n, nb, list(secs)))
         if T is not None:
             T['dec_gpu_seg'] = T.get('dec_gpu_seg', 0) + secs[0]
             T['dec_rans'] = T.get('dec_rans', 0) + secs[1]
@@ -309,7 +339,7 @@ class CodecBase(nn.Module):
     def _encode_group_native(self, pl, cuts, offs, n, tables, nthreads, stream, T=None):
         """Runs the group's whole encode (launches, progressive hand-over, rANS).  -> strings[li][b] (bytes)."""
         from .. import _native
-        arr, _segs, _tail, _nt = self._group_blocks(pl, 'enc', cuts, offs, n)
+        arr, _segs, _tail, _nt, _early = self._group_blocks(pl, 'enc', cuts, offs, n)
         nb = len(cuts)
         qcdf, cdf_len, offset = tables
         caps = [8 * pl.lat_shapes[li][0] * pl.lat_shapes[li][1] + 64 for li in range(nb)]
@@ -450,13 +480,19 @@ class CodecBase(nn.Module):
             st.wait_event(ev)
             with torch.cuda.stream(st):
                 return fn(g, groups[g][0], groups[g][1], st)
-        futs = [self._pool.submit(work, g) for g in range(len(groups))]
-        res, err = [], None
+        # the last group runs on the calling thread (no hand-over latency for it; the pool threads have theirs first)
+        futs = [self._pool.submit(work, g) for g in range(len(groups) - 1)]
+        res, err, last = [], None, None
+        try:
+            last = work(len(groups) - 1)
+        except BaseException as e:                        # noqa: BLE001
+            err = e
         for f in futs:                                    # every group finishes before an error is raised: the plans and streams
             try:                                          # of a failed call must be idle when the caller tries again
                 res.append(f.result())
             except BaseException as e:                    # noqa: BLE001
                 err = err or e
+        res.append(last)
         if err is not None:
             raise err
         cur = torch.cuda.current_stream(dev)

@@ -28,12 +28,13 @@ from ..base import CodecBase, PREC_CODE, on_model_device
 from ..entropy_coding import DiscretizedGaussian, rans_decode_streams, rans_encode_streams
 
 EMBED_DIM = 256
-# With `model.side_streams = True` (opt-in), encode plans up to this many pixels per launch run posterior0 and the prior heads on a side
-# stream (single images / small batches: the GPU is far from full and every launch of a branch is latency on the critical path: 0.3 ms
-# of a 9.6 ms single-image encode+decode); larger batches fill the chip anyway.  Off by default: round 2 saw run-to-run different
-# bitstreams with kernels of two streams sharing CUs (traced to a packed-FMA operand form the depthwise kernel no longer uses,
-# csrc/dwconv_cl.hip; never reproduced since) -- results must not depend on it either way, which
-# tests/test_gpu_model.py::test_encode_is_stable_under_stream_concurrency checks with the option ON.
+# `model.side_streams` (default on since round 5): encode plans up to this many pixels per launch run posterior0 and the prior heads on a
+# side stream (single images / small batches: the GPU is far from full and every launch of a branch is latency on the critical path:
+# 0.3 ms of a single-image encode); larger batches fill the chip anyway.  Rounds 2-4 kept it opt-in: round 2 had seen run-to-run
+# different bitstreams with kernels of two streams sharing CUs -- since traced, at ISA level, to a packed-FMA operand form
+# (`op_sel` on src1: tools/ubench/pk_opsel_probe.hip, profiles/r04_ubench_pk_opsel_erratum_probe.txt) that the depthwise kernel no
+# longer uses; the two pipeline groups of every batched call share CUs the same way.  Results do not depend on the option (same
+# kernels, same inputs): tests/test_gpu_model.py::test_encode_is_stable_under_stream_concurrency.
 SIDE_STREAM_MAX_PIXELS = 2 * 512 * 768
 
 
@@ -490,7 +491,7 @@ class VariableRateLossyVAE(CodecBase):
         self._plans = {}
         self._cur_lmb = None
         self.timing = {} if os.environ.get('LVAE_TIMING') else None      # host-side phase timers (debug)
-        self.side_streams = False      # opt-in: independent encoder branches of small launches on a second HIP stream (see SIDE_STREAM_MAX_PIXELS)
+        self.side_streams = True       # independent encoder branches of small launches on a second HIP stream (see SIDE_STREAM_MAX_PIXELS)
 
     # ---- helpers
     def _dg(self) -> DiscretizedGaussian:
@@ -680,7 +681,27 @@ class VariableRateLossyVAE(CodecBase):
         heads = [struct.unpack('f', s[:4]) + struct.unpack('3H', s[4:10]) for s in strings]
         lmb, nB, nH, nW = heads[0]
         assert nB == 1 and all(h == heads[0] for h in heads), 'batch must share lambda and shape'
-        lv = [coding.unpack_byte_string(s[10:]) for s in strings]
+        if not all(isinstance(s, bytes) for s in strings):
+            strings = [bytes(s) for s in strings]
+        lv = None if self.native_group_loops else [coding.unpack_byte_string(s[10:]) for s in strings]
+
+        def stream_views(start, n, nb):
+            """[image][block] -> (container, offset, length): the container's payloads (utils/coding.py: 'B' count, count x 'I' lengths,
+            payloads) as views -- the native decode loop reads them in place, nothing is sliced out (2.4 MB of copies per batch of 8)."""
+            out = []
+            for b in range(n):
+                s = strings[start + b]
+                num = s[10]
+                lengths = struct.unpack_from(f'{num}I', s, 11)
+                o = 11 + 4 * num
+                assert num == nb, f'expected {nb} strings per image'
+                assert sum(lengths) == len(s) - o, f'{sum(lengths)=} should equal to {len(s) - o=}'
+                v = []
+                for ln in lengths:
+                    v.append((s, o, ln))
+                    o += ln
+                out.append(v)
+            return out
         t_a = time.time()
         self._prepare()
         self._set_lmb(lmb)
@@ -698,15 +719,17 @@ class VariableRateLossyVAE(CodecBase):
             if T is not None:
                 T['dec_head_thread'] = T.get('dec_head_thread', 0) + time.time() - t_b          # submit -> the group's thread runs
             pl = self._plan('dec', n, nH, nW, g)
-            assert all(len(lv[start + b]) == len(pl.cuts) for b in range(n)), f'expected {len(pl.cuts)} strings per image'
             lo = 0
             if T is not None:
                 T['dec_head'] = T.get('dec_head', 0) + time.time() - t_entry                    # entry -> this group's first launch
             if self.native_group_loops:
+                if g and self.dec_stagger:
+                    time.sleep(g * self.dec_stagger)
                 # the loop below as ONE foreign call (csrc/plan_runtime.cpp::lvae_decode_blocks)
-                self._decode_group_native(pl, pl.cuts, pl.idx_off, n, [lv[start + b] for b in range(n)], tables, nthreads, stream, T)
+                self._decode_group_native(pl, pl.cuts, pl.idx_off, n, lambda: stream_views(start, n, len(pl.cuts)), tables, nthreads, stream, T)
                 out[start:start + n].copy_(pl.out, non_blocking=True)
                 return None
+            assert all(len(lv[start + b]) == len(pl.cuts) for b in range(n)), f'expected {len(pl.cuts)} strings per image'
             for li, cut in enumerate(pl.cuts):
                 t0 = time.time()
                 pl.run(lo, cut, stream=stream.cuda_stream)

@@ -404,14 +404,16 @@ def test_prior_sampling_statistics_and_determinism(product_model):
 
 
 def test_encode_is_stable_under_stream_concurrency(product_model):
-    """Byte-compare stress: kernels of two HIP streams share the CUs in two situations -- the opt-in side stream of small
+    """Byte-compare stress: kernels of two HIP streams share the CUs in two situations -- the side stream of small
     encode plans (posterior0 / prior head beside the main branch) and the two pipeline groups of a batch.  Encoding the same input over
     and over must give the same bytes every time, the same as with the side stream off, and batch == single."""
     m = product_model
     im = _img(512, 768, 5).cuda()
-    ref = m.compress(im, 700.0)
-    m.side_streams = True
+    was = m.side_streams
     try:
+        m.side_streams = False
+        ref = m.compress(im, 700.0)
+        m.side_streams = True
         outs = {m.compress(im, 700.0) for _ in range(40)}
         assert outs == {ref}, f'{len(outs)} different bitstreams with the side stream on'
         small = _img(128, 192, 6).cuda()
@@ -420,7 +422,7 @@ def test_encode_is_stable_under_stream_concurrency(product_model):
         m.side_streams = True
         assert {m.compress(small, 64.0) for _ in range(60)} == {ref_small}
     finally:
-        m.side_streams = False
+        m.side_streams = was
     ims = torch.cat([_img(256, 384, 400 + i) for i in range(8)], 0).cuda()
     first = m.compress_batch(ims, 300.0)
     for _ in range(15):
