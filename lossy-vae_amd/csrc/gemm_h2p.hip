@@ -51,12 +51,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // without workspace traffic or a second launch.  The host takes it when the BATCH gives enough tiles to fill the chip; the slice count
 // itself stays a function of the per-image shape (lvae/engine.py::auto_ksplit), so batched and single-image calls agree bit for bit.
 template <int WM, int TN, int NBUF, bool FOLD = false>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2))) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
     using C = Cfg<WM, 2, 2, TN, 1, 32>;
     constexpr int BM = 64 * WM, BN = 64 * TN, ROWS = BM + BN, STAGE = ROWS * 128;
     constexpr int NWAVE = 2 * WM, NG = ROWS / 8, NI = NG / NWAVE;       // DMA instructions per stage, per wave and stage
     static_assert(NG % NWAVE == 0 && NWAVE % 2 == 0, "whole DMA instructions per wave; g has the parity of the wave");
-    static_assert(NBUF * STAGE <= 160 * 1024 / (WM == 4 ? 1 : 2), "LDS");
+    static_assert(NBUF * STAGE <= 160 * 1024 / (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2)), "LDS");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int t;
     {
@@ -316,7 +316,7 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
 #ifdef LVAE_EXP_H2PP
     if ((sel == 92 || sel == 91) && d->K >= 128 && !(d->K & 63)) { *rc = lvae_gemm_h2pp_launch(d, st, sel - 90); return 1; }
 #endif
-    if (sel != 42 && sel != 41 && sel != 22 && sel != 21) {
+    if (sel != 42 && sel != 41 && sel != 22 && sel != 21 && sel != 23) {
         // Tile by measurement (profiles/r03_gemm_h2p_tile_sweep.txt: every MLP shape of the model at batch 4 and 8 under each tile):
         // least padded width first (N = 192: three 64-wide tiles, not two 128-wide); 64-wide: 128 x 64 everywhere; 128-wide: 128 x 64
         // while 128 x 128 tiles would be fewer than ~4 per CU (the mid-size launches of one pipeline group: more, smaller workgroups
@@ -324,11 +324,19 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
         const int tn = (N % 128 == 0 || ((N + 127) / 128) * 128 - N < ((N + 63) / 64) * 64 - N + 1) ? 2 : 1;
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         sel = tn == 1 ? 21 : (t128 < 1024 ? 21 : (t128 >= 4096 ? 42 : 22));
+        // Round 5: the 128 x 64 tile with TWO ring slots (48 KB of LDS: three workgroups per CU instead of two; its 164 registers allow
+        // three waves per SIMD anyway).  One stage less of DMA look-ahead against a third workgroup whose epilogue can run under the
+        // other two's main loops: -2 ... -7 % where the K loop is short and the tiles are many, +5 ... +60 % on the few-tile long-K
+        // layers (profiles/r05_gemm_h2p_three_workgroups_per_cu.txt) -- taken for K <= 512 with at least two tiles per slot-pair
+        const long t64 = (long)((M + 127) / 128) * ((N + 63) / 64);
+        if (d->K <= 512 && t64 >= 512 && (sel == 21 || (sel == 22 && t128 < 2048))) sel = 23;
     }
     switch (sel) {
         case 42: *rc = launch_h2p<4, 2, 3>(d, st); break;
         case 41: *rc = launch_h2p<4, 1, 3>(d, st); break;
         case 22: *rc = launch_h2p<2, 2, 2>(d, st); break;
+        case 23: *rc = launch_h2p<2, 1, 2>(d, st); break;      // 128 x 64, two ring slots (48 KB): three workgroups per CU
+
         default: *rc = launch_h2p<2, 1, 3>(d, st); break;
     }
     return 1;

@@ -219,7 +219,6 @@ class CodecBase(nn.Module):
         # concurrently from their threads -- the same plans and launches as the product configuration, but a launch bracketed by HIP
         # events on its stream is then alone on the GPU
         self.serial_groups = False
-        self.dec_stagger = float(os.environ.get('LVAE_DEC_STAGGER_MS', '0')) * 1e-3     # EXPERIMENT (r5): group g starts its decode g * stagger late
         # default: fp32-class accuracy on the bf16 matrix cores (same parity as the exact fp32 MFMA path, 1.2-1.5x faster)
         self._prec = DEFAULT_PRECISION
 

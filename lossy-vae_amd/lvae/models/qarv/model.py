@@ -328,8 +328,15 @@ class _EncPlan(_NetPlan):
         super().__init__(model, pk, B)
         lib = self.lib
         self.im = self.new(B * 3 * H * W)
-        if getattr(model, 'side_streams', False) and B * H * W <= SIDE_STREAM_MAX_PIXELS:
+        if getattr(model, 'side_streams', False):
             self.enable_side_stream()
+        # small plans: every block's posterior0 and prior head beside the main branch (pure launch latency there)
+        small_side = self.side_stream is not None and B * H * W <= SIDE_STREAM_MAX_PIXELS
+        # every plan: posterior0 of the stride-8 / 16 latent blocks -- a ConvNeXt block on the ENCODER feature alone (qarv/model.py:58-59),
+        # the only large launches of the encode that do not sit on its dependency chain -- is hoisted to the point where the bottom-up
+        # path leaves stride 16 and runs on the side stream under the stride-32 / 64 stages of both paths, whose launches (M = 96 ... 384
+        # rows per image) leave the chip almost empty (round 5; same kernels, same inputs, same bits)
+        hoisted = {}                                    # dec_blocks index -> buffer holding posterior0's output
         self.alloc_latent_io(H // 64, W // 64)
         self.nats = self.new(model.num_latents * B, torch.float64) if with_bits else None   # [block][image] sum(-ln P)
         feats = {}
@@ -345,6 +352,8 @@ class _EncPlan(_NetPlan):
                                              m.out_channels, model.im_shift, model.im_scale, self.status_ptr()), p + '.stem')
                 self.flops += 2 * B * h * w * m.out_channels * 48
             elif m.kind == 'down':
+                if self.side_stream is not None and (h, w) == (H // 16, W // 16) and not hoisted:
+                    self._hoist_posterior0(model, feats, hoisted, H, W)
                 h, w = h // 2, w // 2
                 nx = self.new(B * h * w * m.out_channels, self.adt)
                 self.gemm(A0=x.data_ptr(), K0=m.in_channels, M=B * h * w, N=m.out_channels, K=4 * m.in_channels,
@@ -372,18 +381,25 @@ class _EncPlan(_NetPlan):
                 M, z = B * h * w, m.zdim
                 ef, eh, ew = feats[m.enc_key]
                 assert (eh, ew) == (h, w)
-                e = self.buf('post_e', M * m.enc_width, self.adt)
                 g = self.buf('post_g', M * m.width, self.adt)
                 mg = self.buf('post_m', M * m.width, self.adt)
-                # posterior0 works on the ENCODER feature only (qarv/model.py:56-70): with a side stream it runs beside resnet_front
-                # (and the prior head beside posterior1) instead of in line with them; both are joined before post_merge
-                self.fork(p + '.fork_post0')
-                self.side_begin()
-                self.cnx(p + '.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), h, w)
-                self.side_end()
-                pm, ioff = self.prior(p, m, f.data_ptr(), h, w, side_head=True)
+                # posterior0 works on the ENCODER feature only (qarv/model.py:56-70): hoisted (above), or -- small plans -- on the side
+                # stream beside resnet_front (and the prior head beside posterior1), or in line; side work is joined before post_merge
+                if i in hoisted:
+                    e = hoisted[i]
+                else:
+                    e = self.buf('post_e', M * m.enc_width, self.adt)
+                    if small_side:
+                        self.fork(p + '.fork_post0')
+                        self.side_begin()
+                    self.cnx(p + '.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), h, w)
+                    self.side_end()
+                # (prior heads on the side stream in EVERY plan were measured too: +0.27 ms per encode at batch 8, profiles/r05_ab_encode_side_stream.txt)
+                head_side = small_side
+                pm, ioff = self.prior(p, m, f.data_ptr(), h, w, side_head=head_side)
                 self.cnx(p + '.posterior1', m.posterior1, f.data_ptr(), g.data_ptr(), h, w)
-                self.join(p + '.join')
+                if head_side or i in hoisted:
+                    self.join(p + '.join')
                 self.gemm(A0=g.data_ptr(), K0=m.width, A1=e.data_ptr(), K1=m.enc_width, lda1=m.enc_width, M=M, N=m.width,
                           Wt=pk.p(p + '.post_merge.w'), bias=pk.p(p + '.post_merge.b'), out=mg.data_ptr(),
                           label=p + '.post_merge')
@@ -412,6 +428,27 @@ class _EncPlan(_NetPlan):
                 h, w = h * m.rate, w * m.rate
             elif m.kind == 'stop':
                 break                                                     # qarv/model.py:310-312
+
+
+    def _hoist_posterior0(self, model, feats, hoisted, H, W):
+        """Record posterior0 of every latent block whose encoder feature is already there (strides 8 and 16) on the side stream,
+        the blocks the top-down path reaches first (stride 16) first."""
+        todo, s = [], 1
+        for i, m in enumerate(model.dec_blocks):
+            if m.kind == 'vrlv' and m.enc_key in feats:
+                todo.append((i, m))
+            elif m.kind == 'stop':
+                break
+        if not todo:
+            return
+        self.fork('hoist.fork')
+        self.side_begin()
+        for i, m in todo:                               # dec_blocks order = the order the top-down path needs them in
+            ef, eh, ew = feats[m.enc_key]
+            e = self.new(self.B * eh * ew * m.enc_width, self.adt)
+            self.cnx(f'dec_blocks.{i}.posterior0', m.posterior0, ef.data_ptr(), e.data_ptr(), eh, ew)
+            hoisted[i] = e
+        self.side_end()
 
 
 class _DecPlan(_NetPlan):
@@ -491,7 +528,8 @@ class VariableRateLossyVAE(CodecBase):
         self._plans = {}
         self._cur_lmb = None
         self.timing = {} if os.environ.get('LVAE_TIMING') else None      # host-side phase timers (debug)
-        self.side_streams = True       # independent encoder branches of small launches on a second HIP stream (see SIDE_STREAM_MAX_PIXELS)
+        # independent encoder branches on a second HIP stream (see SIDE_STREAM_MAX_PIXELS, _EncPlan); LVAE_SIDE_STREAMS=0: A/B switch, same bits
+        self.side_streams = os.environ.get('LVAE_SIDE_STREAMS', '1') == '1'
 
     # ---- helpers
     def _dg(self) -> DiscretizedGaussian:
@@ -723,8 +761,6 @@ class VariableRateLossyVAE(CodecBase):
             if T is not None:
                 T['dec_head'] = T.get('dec_head', 0) + time.time() - t_entry                    # entry -> this group's first launch
             if self.native_group_loops:
-                if g and self.dec_stagger:
-                    time.sleep(g * self.dec_stagger)
                 # the loop below as ONE foreign call (csrc/plan_runtime.cpp::lvae_decode_blocks)
                 self._decode_group_native(pl, pl.cuts, pl.idx_off, n, lambda: stream_views(start, n, len(pl.cuts)), tables, nthreads, stream, T)
                 out[start:start + n].copy_(pl.out, non_blocking=True)

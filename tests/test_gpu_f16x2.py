@@ -245,7 +245,7 @@ def test_gemm_f16x2_rejects_what_it_does_not_take():
 
 
 # ---------------------------------------------------------------------------------------------- pre-split operands (csrc/gemm_h2p.hip)
-@pytest.mark.parametrize('tile', [42, 41, 22, 21, 0])
+@pytest.mark.parametrize('tile', [42, 41, 22, 21, 23, 0])
 @pytest.mark.parametrize('M,N,K,epi', [(1000, 384, 192, 1), (256, 128, 32, 0), (3001, 192, 384, 2), (520, 448, 256, 1), (12288, 768, 384, 1),
                                        (777, 64, 1536, 2), (40000, 384, 128, 1), (70001, 192, 384, 2)])
 def test_gemm_h2p_equals_h2_bit_for_bit(M, N, K, epi, tile):
