@@ -298,6 +298,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--serial-groups', action='store_true',
+                    help='PROFILING ONLY: the pipeline groups of every call run one after the other (the same plans and launches as the product '
+                         'configuration, each launch alone on the GPU) -- what the roofline pass times with HIP events; under rocprofv3 this gives the '
+                         'per-kernel durations that `roofline.avg_launch_us` is to be compared with.  The headline value of such a run is NOT the metric.')
     ap.add_argument('--precision', type=str, default='f16x2', choices=['fp32', 'f16x2', 'bf16x3', 'bf16', 'fp8'],
                     help="GEMM arithmetic: f16x2 (default) = fp32-class accuracy from 2-term fp16 splits, 3 fp16 MFMAs per product step; "
                          "bf16x3 = the same from exact 3-term bf16 splits (6 MFMAs); "
@@ -354,6 +358,7 @@ def main():
     else:
         model.coder_threads = max(8, len(os.sched_getaffinity(0)) // max(1, world))      # the cores this process may use, not the machine's
     model.set_gemm_precision(args.precision)
+    model.serial_groups = bool(args.serial_groups)
     ims = synth_batch(B, H, W, rank).to(dev)
 
     def step():
@@ -657,7 +662,7 @@ def main():
                       'bf16': 'bf16-mfma (f32 activations/accumulate; NOT the parity path)',
                       'fp8': 'mxfp8-mfma (OCP e4m3 + E8M0 block scales, f32 accumulate) with bf16 activation storage: BASELINE config 5, '
                              'NOT the parity path'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
+            'config': {'workload': ('PROFILING RUN (--serial-groups: NOT the metric) ' if args.serial_groups else '') + f'qarv_base batch={B} {H}x{W} synthetic per GPU, compress_batch+decompress_batch, '
                                    f'HIP kernels ({args.precision}) + host rANS, seeded random-init weights (profile {PROFILE})', 'global_batch': world * B,
                        'parallelism': f'dp{world} (images sharded, no data-path collective)',
                        'lambda': model.default_lmb},
