@@ -55,16 +55,63 @@ __device__ __forceinline__ lvae_f2 lvae_erff2(lvae_f2 a) {
     o[1] = t[1] > 0.927734375f ? copysignf(1.0f - __expf(r[1]), a[1]) : q[1];
     return o;
 }
+// GELU's erf, ONE branch (round 5).  The two-branch erf above (kept for the likelihood kernel, which needs differences of erf values to
+// RELATIVE accuracy) evaluates BOTH polynomials -- 13 FMAs -- plus a product by log2(e), a compare and a select per element: 31 VALU
+// instructions per two elements, ~17 of the ~27 slots an fc1 epilogue spends per hidden element, in phases that run at the vector pipe's
+// rate with the matrix pipe idle.  GELU needs erf to ABSOLUTE accuracy only (it is multiplied by x / 2), so the cancellation
+// of 1 - exp(.) near 0 -- the reason for the second branch -- is harmless here:
+//     erf(z) = sign(z) (1 - 2^(t q(t))),  t = min(|z|, 4),  q of degree 7        (1 - erf(4) = 1.5e-8: rounds to 1)
+// (weighted minimax fit of log2(erfc(t)) / t on [0, 4]: tools/fit_gelu_erf.py), and  gelu(x) = fma(x / 2, erf, x / 2)  -- one rounding
+// less than (x / 2) (1 + erf).  18 VALU instructions per two elements (7 FMAs + 1 product + v_exp_f32 with log2(e) folded into q).
+// fp32-evaluated accuracy: erf max |error| 9.8e-8, GELU 8.9e-8 max(1, |x|) -- the two-branch form's GELU: 1.1e-7 (its last two
+// roundings) -- tests/test_gpu_kernels.py::test_gelu_erf_accuracy (bar 2e-7).  Seven candidate forms (degree 7 / 8 / 9, two fits,
+// with / without the final fma) were run against every reference golden: six keep all of them flip-free, this one is the cheapest
+// and the most accurate of them (profiles/r05_gelu_single_branch_study.txt).
+// Scalar and packed forms apply the same IEEE operations per element (explicit fma, no contraction): identical bits.
+#define LVAE_GQ0 (-1.6279085874557495f)
+#define LVAE_GQ1 (-0.9184163808822632f)
+#define LVAE_GQ2 (-0.14848165214061737f)
+#define LVAE_GQ3 (0.028253760188817978f)
+#define LVAE_GQ4 (-0.0007747217314317822f)
+#define LVAE_GQ5 (-0.001489384681917727f)
+#define LVAE_GQ6 (0.00044549000449478626f)
+#define LVAE_GQ7 (-4.535645348369144e-05f)
+__device__ __forceinline__ float lvae_gelu_erf1(float z) {
+#pragma clang fp contract(off)
+    const float t = fminf(fabsf(z), 4.0f);
+    float r = fmaf(LVAE_GQ7, t, LVAE_GQ6);
+    r = fmaf(r, t, LVAE_GQ5);
+    r = fmaf(r, t, LVAE_GQ4);
+    r = fmaf(r, t, LVAE_GQ3);
+    r = fmaf(r, t, LVAE_GQ2);
+    r = fmaf(r, t, LVAE_GQ1);
+    r = fmaf(r, t, LVAE_GQ0);
+    return copysignf(1.0f - __builtin_amdgcn_exp2f(r * t), z);
+}
 __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
 #pragma clang fp contract(off)
     const lvae_f2 x = {x0, x1};
-    const lvae_f2 e = lvae_erff2(x * (lvae_f2)(0.70710678118654752440f));
-    const lvae_f2 g = ((lvae_f2)(0.5f) * x) * ((lvae_f2)(1.0f) + e);
+    const lvae_f2 z = x * (lvae_f2)(0.70710678118654752440f);
+    const lvae_f2 t = {fminf(fabsf(z[0]), 4.0f), fminf(fabsf(z[1]), 4.0f)};
+    lvae_f2 r = __builtin_elementwise_fma((lvae_f2)(LVAE_GQ7), t, (lvae_f2)(LVAE_GQ6));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ5));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ4));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ3));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ2));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ1));
+    r = __builtin_elementwise_fma(r, t, (lvae_f2)(LVAE_GQ0));
+    const lvae_f2 p = r * t;
+    lvae_f2 e;
+    e[0] = copysignf(1.0f - __builtin_amdgcn_exp2f(p[0]), z[0]);
+    e[1] = copysignf(1.0f - __builtin_amdgcn_exp2f(p[1]), z[1]);
+    const lvae_f2 h = (lvae_f2)(0.5f) * x;
+    const lvae_f2 g = __builtin_elementwise_fma(h, e, h);
     x0 = g[0]; x1 = g[1];
 }
 
 // exact-erf GELU (nn.GELU() default; lvae/models/common.py:124,132)
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)
-    return 0.5f * x * (1.0f + lvae_erff(x * 0.70710678118654752440f));
+    const float h = 0.5f * x;
+    return fmaf(h, lvae_gelu_erf1(x * 0.70710678118654752440f), h);
 }

@@ -16,6 +16,11 @@ for p in (REPO, PKG, os.path.join(REPO, 'tests')):
 
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
+if os.environ.get('LVAE_LIB'):       # study builds only (tools/build_exp.sh, tools/build_gelu_variants.sh): run the suite against another library
+    from lvae import _native as _nat
+    _nat.LIB_PATH = os.path.abspath(os.environ['LVAE_LIB'])
+    print(f'[conftest] LVAE_LIB: testing {_nat.LIB_PATH}', file=sys.stderr)
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (HIP kernels run); skipped by -m "not gpu"')
