@@ -314,7 +314,7 @@ def main():
                          'each of compress / decompress) after the timed region -> b1 (0 = skip)')
     ap.add_argument('--qres-steps', type=int, default=5,
                     help='extra steps of BASELINE config 3 (qres34m, 8 x 512x768, seeded weights) after the timed region -> qres34m_value (0 = skip)')
-    ap.add_argument('--config5-steps', type=int, default=5,
+    ap.add_argument('--config5-steps', type=int, default=8,
                     help='extra steps of BASELINE config 5 (fp8 mode, 4 x 1216x1216) after the timed region -> config5_value (0 = skip)')
     args = ap.parse_args()
 
@@ -581,7 +581,7 @@ def main():
                 o5 = model.decompress_batch(s5)
                 torch.cuda.synchronize(dev)
                 return s5, o5, tm
-            for _ in range(2):
+            for _ in range(3):
                 step5()
             t1 = time.time()
             te5 = 0.0
@@ -612,7 +612,7 @@ def main():
                 step5()
             t1 = time.time()
             tef = 0.0
-            nf = max(2, args.config5_steps // 2)
+            nf = max(4, args.config5_steps // 2)
             for _ in range(nf):
                 ts = time.time()
                 _, _, tm = step5()

@@ -18,14 +18,20 @@ ims = bench.synth_batch(B, 512, 768, 0).to(dev)
 models = []
 for sp in specs:
     g, side = (int(v) for v in sp.split(',')[:2])
+    fused384 = int(sp.split(',')[2]) if len(sp.split(',')) > 2 else None      # third field: row threshold of the (384, 768) fused MLP while this variant's plans are built
     m, _ = bench.build_model(dev)
     m.coder_threads = max(8, len(os.sched_getaffinity(0)))
     m.enc_groups, m.side_streams = g, bool(side)
+    from lvae import engine
+    saved_rows = dict(engine.Plan.FUSED_MLP_MIN_ROWS)
+    if fused384 is not None:
+        engine.Plan.FUSED_MLP_MIN_ROWS = {(384, 768): fused384}
     m._invalidate() if False else None
     ref = None
     for _ in range(4):
         s = m.compress_batch(ims)
         torch.cuda.synchronize()
+    engine.Plan.FUSED_MLP_MIN_ROWS = saved_rows
     models.append((sp, m, s))
 assert all(s == models[0][2] for _, _, s in models), 'variants must produce the same bytes'
 rounds, steps = int(os.environ.get('AB_ROUNDS', '8')), int(os.environ.get('AB_STEPS', '15'))

@@ -1,7 +1,6 @@
-# same-process A/B of encode variants (tools/ab_enc.py): pipeline groups x side stream
+# same-process A/B of encode variants (tools/ab_enc.py): pipeline groups x side stream [x row threshold of the (384, 768) fused MLP]
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5_ab
 mkdir -p $O
 cd $R
-python tools/ab_enc.py "2,1" "2,0" "1,1" "1,0" 2>&1 | grep -v amdgpu | grep "enc groups" | tee $O/ab_enc_b8.txt
-AB_BATCH=1 python tools/ab_enc.py "1,1" "1,0" 2>&1 | grep -v amdgpu | grep "enc groups" | tee $O/ab_enc_b1.txt
+python tools/ab_enc.py "2,1" "2,1,24576" "2,0" "1,1" 2>&1 | grep -v amdgpu | grep "enc groups" | tee $O/ab_enc_b8_fused384.txt

@@ -2,7 +2,10 @@
 """Determinism soak of the product path on one MI355X: for `--seconds` of wall time, keep encoding and decoding the same seeded
 inputs and compare every result with the first one, bit for bit --
 
-  * compress_batch (two pipeline groups, two streams)      -> byte strings == first run's
+  * compress_batch with model.side_streams = False (two pipeline groups, two streams; the reference strings come from this form)
+                                                            -> byte strings == first run's
+  * compress_batch with the side stream (the product default since round 5: two groups x (main + side stream), posterior0 of the
+    stride-8 / 16 blocks hoisted)                           -> == the same strings
   * single-image compress of one image of the batch        -> == that image's string of the batch call (batch invariance)
   * single-image compress with model.side_streams = True   -> == the same string (fork/join plan)
   * decompress_batch                                        -> reconstruction bits == first run's
@@ -55,7 +58,7 @@ def main():
         ref_strings = model.compress_batch(x)
         ref_rec = model.decompress_batch(ref_strings).clone()
         cases.append((H, W, x, ref_strings, ref_rec))
-    counts = {'compress_batch': 0, 'compress_single': 0, 'compress_single_side_streams': 0, 'decompress_batch': 0, 'decompress_single': 0}
+    counts = {'compress_batch': 0, 'compress_batch_side_streams': 0, 'compress_single': 0, 'compress_single_side_streams': 0, 'decompress_batch': 0, 'decompress_single': 0}
     bad = {k: 0 for k in counts}
     t0 = time.time()
     it = 0
@@ -66,6 +69,11 @@ def main():
         s = model.compress_batch(x)
         counts['compress_batch'] += 1
         bad['compress_batch'] += int(s != ref_strings)
+        model.side_streams = True
+        sb = model.compress_batch(x)
+        model.side_streams = False
+        counts['compress_batch_side_streams'] += 1
+        bad['compress_batch_side_streams'] += int(sb != ref_strings)
         s1 = model.compress(x[i:i + 1])
         counts['compress_single'] += 1
         bad['compress_single'] += int(s1 != ref_strings[i])
