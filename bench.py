@@ -606,7 +606,7 @@ def main():
                          'measured_over': "2 extra steps on this configuration's own plans (groups replayed one after the other, launch by launch), HIP events around every such launch"}
                 attach_traffic(roof5, 'fp8', 4, 1216, 1216)
             # the same workload under the fp32-class arithmetic of the headline: encode and decode ratios separately (the decode half is
-            # bound by one image's serial rANS -- 2.3 M symbols -- whatever the GPU does: DESIGN.md 5c)
+            # bound by one image's serial rANS -- 2.3 M symbols -- whatever the GPU does: docs/MEASUREMENT_HISTORY.md 5c)
             model.set_gemm_precision(args.precision)
             for _ in range(2):
                 step5()

@@ -31,7 +31,7 @@ __device__ __forceinline__ float lvae_erff(float a) {
 }
 
 // Two-element form on packed f32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes-worth of FMAs per VALU issue).  f32 MFMA and VALU
-// do not overlap on a SIMD, so every VALU instruction in an epilogue is serial time: the polynomial halves.
+// do not overlap on a SIMD (docs/MEASUREMENT_HISTORY.md 5), so every VALU instruction in an epilogue is serial time: the polynomial halves.
 typedef float lvae_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lvae_f2 lvae_erff2(lvae_f2 a) {
 #pragma clang fp contract(off)
@@ -58,7 +58,7 @@ __device__ __forceinline__ lvae_f2 lvae_erff2(lvae_f2 a) {
 // GELU's erf, ONE branch (round 5).  The two-branch erf above (kept for the likelihood kernel, which needs differences of erf values to
 // RELATIVE accuracy) evaluates BOTH polynomials -- 13 FMAs -- plus a product by log2(e), a compare and a select per element: 31 VALU
 // instructions per two elements, ~17 of the ~27 slots an fc1 epilogue spends per hidden element, in phases that run at the vector pipe's
-// rate with the matrix pipe idle.  GELU needs erf to ABSOLUTE accuracy only (it is multiplied by x / 2), so the cancellation
+// rate with the matrix pipe idle (docs/MEASUREMENT_HISTORY.md 5d).  GELU needs erf to ABSOLUTE accuracy only (it is multiplied by x / 2), so the cancellation
 // of 1 - exp(.) near 0 -- the reason for the second branch -- is harmless here:
 //     erf(z) = sign(z) (1 - 2^(t q(t))),  t = min(|z|, 4),  q of degree 7        (1 - erf(4) = 1.5e-8: rounds to 1)
 // (weighted minimax fit of log2(erfc(t)) / t on [0, 4]: tools/fit_gelu_erf.py), and  gelu(x) = fma(x / 2, erf, x / 2)  -- one rounding

@@ -9,7 +9,7 @@
 #include "../../include/lvae_hip.h"
 #include "device_math.h"
 
-// Experiment hooks of the round-1/2 kernel studies.  LVAE_EXP_NOSPLIT / LVAE_EXP_NOSTORE / LVAE_GEMM_NOLOAD give WRONG
+// Experiment hooks of the round-1/2 kernel studies (docs/MEASUREMENT_HISTORY.md 5, 5b).  LVAE_EXP_NOSPLIT / LVAE_EXP_NOSTORE / LVAE_GEMM_NOLOAD give WRONG
 // RESULTS by construction (they remove work to time what is left); the others change scheduling only.  None of them can be switched on
 // in the product build: they compile only together with -DLVAE_EXPERIMENTAL_BUILD, which tools/build_exp.sh passes for its
 // side-by-side copies under _bin/ and lossy-vae_amd/build_native.py never does.

@@ -259,7 +259,7 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
     if (const int ae = attr.ensure((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, LDS)) return ae;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     static int lds_pad = 0, stagger = 0;
-#ifdef LVAE_EXPERIMENTAL_BUILD           // knobs of the round-3 studies (tools/build_exp.sh copies only): extra dynamic LDS (forces
+#ifdef LVAE_EXPERIMENTAL_BUILD           // knobs of the round-3 studies (tools/build_exp.sh copies only; docs/MEASUREMENT_HISTORY.md 5c): extra dynamic LDS (forces
     static bool env_read = false;        // one 128-row workgroup per CU) and the phase stagger (measured 0 ... -5 % on the model's shapes)
     if (!env_read) {
         const char* e = getenv("LVAE_H2P_LDSPAD"); lds_pad = e ? atoi(e) : 0;

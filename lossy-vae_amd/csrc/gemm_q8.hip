@@ -4,7 +4,7 @@
 // scales directly -- 1.03 bytes per element instead of bf16's 2.
 //
 // Why.  gemm_lp_kernel (gemm_lp.hip) quantises A on its way into LDS: 2 500 VALU instructions per wave against 24 MFMAs, 0.25 of the
-// HBM roof.  This mode is HBM-bound by construction (a 4.6 PFLOP/s matrix pipe), so the main loop here does no arithmetic
+// HBM roof (docs/MEASUREMENT_HISTORY.md 5b).  This mode is HBM-bound by construction (a 4.6 PFLOP/s matrix pipe), so the main loop here does no arithmetic
 // besides the MFMAs: global -> LDS by `buffer_load_dwordx4 ... lds` for data and scales, fragment reads, v_mfma_scale_f32_32x32x64_f8f6f4.
 //
 // Operand format Q8 of an [R][K] matrix (K % 64 == 0): R*K e4m3 bytes row-major, then the E8M0 scales as [K/64][R][2] (one pair per row

@@ -136,7 +136,7 @@ extern "C" int lvae_build_gaussian_tables(const float* scale_table, int n_scales
 
 // Encoder symbol entries.  rANS's encode step is x' = ((x / freq) << 16) + (x % freq) + start: a 64-bit division (25-40 cycles of
 // latency on the host cores) in the serial dependency chain of EVERY symbol -- 7.8 ns per symbol against the decoder's 2.4
-// (tools/rans_bench.py), and the encoder's backlog is what the GPU's last latent block waits behind (DESIGN.md 5e).  The quotient
+// (tools/rans_bench.py), and the encoder's backlog is what the GPU's last latent block waits behind (DESIGN.md 5.1).  The quotient
 // comes from a reciprocal instead (Alverson, "Integer division using reciprocals"; the form of ryg's rans64.h): with
 // l = ceil(log2 freq) and m = ceil(2^(63 + l) / freq), floor(x / freq) == mulhi64(x, m) >> (l - 1) for every x < 2^63 (the coder's
 // state is < 2^47 * freq <= 2^63 after the renormalisation check), and x' = x + start + q * (65536 - freq).  freq == 1 has no

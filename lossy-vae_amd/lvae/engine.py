@@ -147,7 +147,7 @@ class _EventHolder:
 
 
 class Plan:
-    autotune = os.environ.get('LVAE_AUTOTUNE', '0') == '1'    # opt-in: in-situ gains were within noise
+    autotune = os.environ.get('LVAE_AUTOTUNE', '0') == '1'    # opt-in: in-situ gains were within noise (docs/MEASUREMENT_HISTORY.md 5)
 
     def __init__(self, device):
         self.lib = _native.lib()
