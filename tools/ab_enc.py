@@ -26,8 +26,6 @@ for sp in specs:
     saved_rows = dict(engine.Plan.FUSED_MLP_MIN_ROWS)
     if fused384 is not None:
         engine.Plan.FUSED_MLP_MIN_ROWS = {(384, 768): fused384}
-    m._invalidate() if False else None
-    ref = None
     for _ in range(4):
         s = m.compress_batch(ims)
         torch.cuda.synchronize()
