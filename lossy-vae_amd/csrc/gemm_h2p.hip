@@ -30,6 +30,9 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef H2P_FULL_LINE
+#define H2P_FULL_LINE true
+#endif
 // timing ablations (wrong results by construction; tools/build_exp.sh only): what a launch costs without its MFMAs / fragment reads / epilogue
 #if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2P_EXP_NOMFMA) || defined(H2P_EXP_NODSR) || defined(H2P_EXP_NOEPI) || defined(H2P_EXP_NODMA))
 #error "H2P_EXP_* ablations need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
@@ -44,6 +47,86 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #else
 #define H2P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
+
+// Straight-line epilogue for the launches this kernel exists for (fc1: + bias -> GELU -> pre-split store; fc2: + bias, * gamma,
+// + residual -> fp32 store; both row-major on a full-width tile).  gemm_epilogue decides epi / store / out_h2 / residual at RUN time
+// inside its unit loop: every 4-element unit is a chain of uniform branches, its store sits behind an exec-mask branch, and the
+// compiler can neither interleave the units' dependent FMA chains nor keep more than one store in flight.  Here the case is a
+// template parameter, rows beyond M are dropped by the buffer resource's range check (no branch around any access) and the whole
+// wave tile unrolls.  The operations per element and their order are gemm_epilogue's (acc + bias; GELU | * gamma; quad transpose;
+// + residual; split_pair_h2), hence the same bits (tests/test_gpu_f16x2.py::test_gemm_h2p_equals_h2_bit_for_bit).
+// FULL (pre-split output only): quad pairs exchange halves by DPP row shifts so that one lane holds the hi terms of EIGHT consecutive
+// columns (its partner the lo' terms): one 16-B store per lane and 8 rows x 128 B = whole lines per instruction instead of two 8-B
+// stores covering half lines.
+template <int TN, int EPI, bool H2, bool FULL>
+__device__ __forceinline__ void h2p_epilogue_fast(const lvae_gemm_desc& d, f32x16 (&acc)[2][TN], int m0, int n0, int rows_a, int wave_m,
+                                                  int wave_n, int li, int lh) {
+    const int lj = li & 3;
+    float cbias[TN], cgam[TN];
+    int c4[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int colb = n0 + (wave_n * TN + b) * 32;
+        cbias[b] = d.bias ? d.bias[colb + li] : 0.f;
+        cgam[b] = EPI == LVAE_EPI_GAMMA_RES ? d.gamma[colb + li] : 1.f;
+        c4[b] = colb + (li & ~3);
+    }
+    constexpr bool HAS_RES = EPI == LVAE_EPI_GAMMA_RES || EPI == LVAE_EPI_RES;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.out + (long)m0 * d.ldo * 4), 0, rows_a * d.ldo * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? (const char*)d.res + (long)m0 * d.ldres * 4 : (const char*)d.out), 0, HAS_RES ? rows_a * d.ldres * 4 : 0, 0x00020000);
+    const bool odd_quad = (li & 4) != 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        u32x4_t rv[4][TN];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) rv[g][b] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (r * d.ldres + c4[b]) * 4, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;          // tile-local row this lane stores
+            const int rowoff = r * d.ldo * 4;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
+                float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
+                if constexpr (EPI == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+                else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
+                quad_transpose(v0, v1, v2, v3, lj);
+                if constexpr (HAS_RES) {
+                    const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
+                    v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                }
+                if constexpr (H2) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h2(v0, v1, h0, l0);
+                    split_pair_h2(v2, v3, h1, l1);
+                    if constexpr (FULL) {
+                        // even quad: {own hi, partner's hi} = hi of columns c8 .. c8 + 7; odd quad: {partner's lo', own lo'}
+                        const unsigned o2 = __builtin_amdgcn_update_dpp(l0, h0, 0x104, 0xF, 0x5, false);     // row_shl:4 into banks 0, 2
+                        const unsigned o3 = __builtin_amdgcn_update_dpp(l1, h1, 0x104, 0xF, 0x5, false);
+                        const unsigned o0 = __builtin_amdgcn_update_dpp(h0, l0, 0x114, 0xF, 0xA, false);     // row_shr:4 into banks 1, 3
+                        const unsigned o1 = __builtin_amdgcn_update_dpp(h1, l1, 0x114, 0xF, 0xA, false);
+                        const int c8 = c4[b] & ~7;
+                        const int off = rowoff + ((c8 >> 5) << 7) + ((c8 & 31) << 1) + (odd_quad ? 64 : 0);
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){o0, o1, o2, o3}, rsO, off, 0, 0);
+                    } else {
+                        const int off = rowoff + ((c4[b] >> 5) << 7) + ((c4[b] & 31) << 1);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, rsO, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){l0, l1}, rsO, off + 64, 0, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v0, v1, v2, v3}), rsO, rowoff + c4[b] * 4, 0, 0);
+                }
+            }
+        }
+    }
+}
 
 // FOLD ("serial split-K", d.ksplit = S > 1 with a_h2): ONE workgroup walks the S contiguous K slices of its tile and adds their partial sums
 // in slice order -- tot = P_0; tot += P_1; ... with P_s = accH_s + accX_s / 2048 -- then applies splitk_epilogue_store: the operations
@@ -248,6 +331,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
 #ifdef H2P_EXP_NOEPI
     if (accH[0][0][0] == 123.456f) d.out[0] = accH[0][0][1] + accH[1][TN - 1][3];
 #else
+#ifndef H2P_EXP_GENERIC_EPI
+    if (d.store == LVAE_ST_ROWMAJOR && n0 + BN <= d.N && !((d.ldo | d.ldres) & 3)) {          // uniform: one of the straight-line forms
+        if (d.epi == LVAE_EPI_BIAS_GELU && d.out_h2 && !(d.ldo & 31)) {
+            h2p_epilogue_fast<TN, LVAE_EPI_BIAS_GELU, true, H2P_FULL_LINE>(d, accH, m0, n0, rows_a, wave_m, wave_n, li, lh);
+            return;
+        }
+        if (d.epi == LVAE_EPI_GAMMA_RES && !d.out_h2) {
+            h2p_epilogue_fast<TN, LVAE_EPI_GAMMA_RES, false, false>(d, accH, m0, n0, rows_a, wave_m, wave_n, li, lh);
+            return;
+        }
+        if (d.epi == LVAE_EPI_RES && !d.out_h2) {
+            h2p_epilogue_fast<TN, LVAE_EPI_RES, false, false>(d, accH, m0, n0, rows_a, wave_m, wave_n, li, lh);
+            return;
+        }
+    }
+#endif
     gemm_finish<C>(d, accH, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 #endif
 }
