@@ -109,6 +109,29 @@ __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
     x0 = g[0]; x1 = g[1];
 }
 
+// Four elements: the two packed chains of gelu_erf2 advance in lockstep (each v_pk_fma_f32 depends on the one before it: a lone chain
+// issues every other slot; two interleaved chains fill each other's gaps).  Per element the operations are gelu_erf2's: same bits.
+__device__ __forceinline__ void gelu_erf4(float& x0, float& x1, float& x2, float& x3) {
+#pragma clang fp contract(off)
+    const lvae_f2 xa = {x0, x1}, xb = {x2, x3};
+    const lvae_f2 za = xa * (lvae_f2)(0.70710678118654752440f), zb = xb * (lvae_f2)(0.70710678118654752440f);
+    const lvae_f2 ta = {fminf(fabsf(za[0]), 4.0f), fminf(fabsf(za[1]), 4.0f)}, tb = {fminf(fabsf(zb[0]), 4.0f), fminf(fabsf(zb[1]), 4.0f)};
+    lvae_f2 ra = __builtin_elementwise_fma((lvae_f2)(LVAE_GQ7), ta, (lvae_f2)(LVAE_GQ6));
+    lvae_f2 rb = __builtin_elementwise_fma((lvae_f2)(LVAE_GQ7), tb, (lvae_f2)(LVAE_GQ6));
+#define LVAE_G4_STEP(q) ra = __builtin_elementwise_fma(ra, ta, (lvae_f2)(q)); rb = __builtin_elementwise_fma(rb, tb, (lvae_f2)(q));
+    LVAE_G4_STEP(LVAE_GQ5) LVAE_G4_STEP(LVAE_GQ4) LVAE_G4_STEP(LVAE_GQ3) LVAE_G4_STEP(LVAE_GQ2) LVAE_G4_STEP(LVAE_GQ1) LVAE_G4_STEP(LVAE_GQ0)
+#undef LVAE_G4_STEP
+    const lvae_f2 pa = ra * ta, pb = rb * tb;
+    lvae_f2 ea, eb;
+    ea[0] = copysignf(1.0f - __builtin_amdgcn_exp2f(pa[0]), za[0]);
+    ea[1] = copysignf(1.0f - __builtin_amdgcn_exp2f(pa[1]), za[1]);
+    eb[0] = copysignf(1.0f - __builtin_amdgcn_exp2f(pb[0]), zb[0]);
+    eb[1] = copysignf(1.0f - __builtin_amdgcn_exp2f(pb[1]), zb[1]);
+    const lvae_f2 ha = (lvae_f2)(0.5f) * xa, hb = (lvae_f2)(0.5f) * xb;
+    const lvae_f2 ga = __builtin_elementwise_fma(ha, ea, ha), gb = __builtin_elementwise_fma(hb, eb, hb);
+    x0 = ga[0]; x1 = ga[1]; x2 = gb[0]; x3 = gb[1];
+}
+
 // exact-erf GELU (nn.GELU() default; lvae/models/common.py:124,132)
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)

@@ -71,6 +71,35 @@ __device__ __forceinline__ float dpp_xor1(float x) {
 __device__ __forceinline__ float dpp_xor2(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
 }
+// Every call site passes j = lane & 3 (the lane's place in its quad), so the two select masks are the constants 0xAAAA... (odd lanes)
+// and 0xCCCC... (upper lane pair).  Form: each exchange step is ONE v_cndmask_b32_dpp per register -- dst = vcc ? own : dpp(partner's
+// register) -- instead of select + v_mov_dpp + two selects (with two wait states in front of every DPP read of a fresh select): 8 VALU
+// + 4 s_mov per 4 x 4 transpose instead of 16 VALU + 8 idle slots, in epilogues whose time is their VALU issue.  VOP2-DPP reads its
+// mask from VCC only, hence the s_mov pairs; the leading s_nop covers "VALU wrote the source, DPP reads it" (two wait states counting the
+// s_mov) for sources produced right in front of the call; inside, every DPP source is at least three instructions old.
+#ifndef LVAE_QUAD_TRANSPOSE_SELECT_FORM
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int /* j == lane & 3 */) {
+    float n0, n1, n2, n3, o0, o1, o2, o3;
+    asm("s_mov_b64 vcc, %[m1]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %[n1], %[v0], %[v1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"      // odd lane keeps v1, even takes partner's v0
+        "v_cndmask_b32_dpp %[n3], %[v2], %[v3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[m1n]\n\t"
+        "v_cndmask_b32_dpp %[n0], %[v1], %[v0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"      // even lane keeps v0, odd takes partner's v1
+        "v_cndmask_b32_dpp %[n2], %[v3], %[v2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[m2]\n\t"
+        "v_cndmask_b32_dpp %[o3], %[n1], %[n3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"      // upper pair keeps n3, lower takes partner's n1
+        "v_cndmask_b32_dpp %[o2], %[n0], %[n2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[m2n]\n\t"
+        "v_cndmask_b32_dpp %[o1], %[n3], %[n1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"      // lower pair keeps n1, upper takes partner's n3
+        "v_cndmask_b32_dpp %[o0], %[n2], %[n0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3)
+        : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [m1] "s"(0xAAAAAAAAAAAAAAAAull), [m1n] "s"(0x5555555555555555ull),
+          [m2] "s"(0xCCCCCCCCCCCCCCCCull), [m2n] "s"(0x3333333333333333ull)
+        : "vcc");
+    v0 = o0; v1 = o1; v2 = o2; v3 = o3;
+}
+#else
 __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int j) {
     const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
     float t;
@@ -79,6 +108,7 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     t = dpp_xor2(o2 ? v0 : v2); if (o2) v0 = t; else v2 = t;
     t = dpp_xor2(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
 }
+#endif
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));

@@ -93,9 +93,10 @@ __device__ __forceinline__ void h2p_epilogue_fast(const lvae_gemm_desc& d, f32x1
             const int rowoff = r * d.ldo * 4;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
-                float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
-                if constexpr (EPI == LVAE_EPI_BIAS_GELU) { gelu_erf2(v0, v1); gelu_erf2(v2, v3); }
+                const lvae_f2 s01 = (lvae_f2){acc[a][b][4 * g + 0], acc[a][b][4 * g + 1]} + (lvae_f2)(cbias[b]);      // (packed adds)
+                const lvae_f2 s23 = (lvae_f2){acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + (lvae_f2)(cbias[b]);
+                float v0 = s01[0], v1 = s01[1], v2 = s23[0], v3 = s23[1];
+                if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
                 else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
                 quad_transpose(v0, v1, v2, v3, lj);
                 if constexpr (HAS_RES) {

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #ifdef H2C_EXP_NOGELU
                         unsigned h0 = __float_as_uint(v0), l0 = __float_as_uint(v1), h1 = __float_as_uint(v2), l1 = __float_as_uint(v3);
 #else
-                        gelu_erf2(v0, v1); gelu_erf2(v2, v3);
+                        gelu_erf4(v0, v1, v2, v3);
                         quad_transpose(v0, v1, v2, v3, lj);
                         unsigned h0, l0, h1, l1;
                         split_pair_h2(v0, v1, h0, l0);
