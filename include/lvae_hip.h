@@ -242,8 +242,10 @@ int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int
  * indexes on the host / block decoded and its symbols on their way to the device; seconds[2 + 4 n_blocks] = tail issued. */
 typedef struct {
     const lvae_op* ops; int n_ops;
-    const uint8_t* idx_dev; uint8_t* idx_host;        /* n_images * per_image bytes */
-    int32_t* sym_host; int32_t* sym_dev;              /* n_images * per_image int32 */
+    const uint8_t* idx_dev; uint8_t* idx_host;        /* n_images * per_image bytes.  idx_dev = NULL: the segment's prior-index launch was recorded
+                                                         with idx_host (pinned, device-mapped host memory) as its output -- no copy is issued */
+    int32_t* sym_host; int32_t* sym_dev;              /* n_images * per_image int32.  sym_dev = NULL: the NEXT segment's dequantize launch reads
+                                                         sym_host itself (written by the coder before that segment is issued) -- no copy */
     size_t per_image;
 } lvae_dec_block;
 int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings, const size_t* string_len,
@@ -263,8 +265,8 @@ int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images,
  * inside the call. */
 typedef struct {
     const lvae_op* ops; int n_ops;
-    const int32_t* sym_dev; int32_t* sym_host;
-    const uint8_t* idx_dev; uint8_t* idx_host;
+    const int32_t* sym_dev; int32_t* sym_host;        /* sym_dev / idx_dev = NULL: the segment's quantize / prior-index launches wrote the pinned */
+    const uint8_t* idx_dev; uint8_t* idx_host;        /* host arrays themselves (as lvae_dec_block) -- no copies, the event follows the segment  */
     size_t per_image;
 } lvae_enc_block;
 int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap, long* out_len,

@@ -128,7 +128,8 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
         const lvae_dec_block& k = blocks[b];
         const double t0 = now_s();
         int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
-        if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
+        // (idx_dev == NULL: the segment's prior_index launch wrote the pinned host array itself -- include/lvae_hip.h, lvae_dec_block)
+        if (rc == 0 && k.idx_dev) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
         const double t_issued = now_s();
         if (rc == 0) {
             // the segment is ~0.3 ms of GPU work and the coder is waiting for it: poll the stream for a bounded while (the wake-up of a
@@ -160,7 +161,8 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
                 return -75;
             return -74;
         }
-        rc = (int)hipMemcpyAsync(k.sym_dev, k.sym_host, k.per_image * n_images * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        // (sym_dev == NULL: the next segment's dequantize launch reads the pinned host array itself)
+        if (k.sym_dev) rc = (int)hipMemcpyAsync(k.sym_dev, k.sym_host, k.per_image * n_images * sizeof(int32_t), hipMemcpyHostToDevice, st);
         if (rc != 0) {
             if (failed_block) *failed_block = b;
             return rc;
@@ -198,8 +200,8 @@ extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, in
     for (int b = 0; b < n_blocks; ++b) {
         const lvae_enc_block& k = blocks[b];
         int rc = lvae_run_ops(k.ops, k.n_ops, stream, side_stream, &bad);
-        if (rc == 0) rc = (int)hipMemcpyAsync(k.sym_host, k.sym_dev, k.per_image * n_images * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (rc == 0) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
+        if (rc == 0 && k.sym_dev) rc = (int)hipMemcpyAsync(k.sym_host, k.sym_dev, k.per_image * n_images * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (rc == 0 && k.idx_dev) rc = (int)hipMemcpyAsync(k.idx_host, k.idx_dev, k.per_image * n_images, hipMemcpyDeviceToHost, st);
         // the status word travels ONCE, behind the last block's segment (a copy per block was measured: +0.1 ms per encode at batch 8)
         if (rc == 0 && b == n_blocks - 1 && status_dev && status_host) rc = (int)hipMemcpyAsync(status_host, status_dev, sizeof(int), hipMemcpyDeviceToHost, st);
         if (rc == 0) rc = (int)hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);

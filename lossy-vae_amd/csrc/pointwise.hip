@@ -400,61 +400,99 @@ __global__ void prior_sample_kernel(const float* __restrict__ prm, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ entropy parameters
-__global__ void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
-                                   const float* __restrict__ table, int n_scales, float bound, long total, int HW, int z,
-                                   int* __restrict__ status) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*z + c
-    if (e >= total) return;
-    const long m = e / z;
-    const int c = (int)(e - m * z);
-    const float mean = prm[m * 2 * z + c];
-    const float lv = prm[m * 2 * z + z + c];
-    // a NaN / inf prior parameter (an fp16 overflow of the f16x2 arithmetic upstream, include/lvae_hip.h "status word") would become
-    // index 0 / 63 and a NaN mean silently: report it (one atomic per wave that saw one)
-    if (status && !(fabsf(mean) <= 3.4028234664e38f && fabsf(lv) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_PRIOR);
-    // softplus(x + 2.3) - 2.3  (torch: beta=1, threshold=20)
-    const float xs = lv + 2.3f;
-    const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
-    const float pv = expf(sp - 2.3f);
-    const float s = fmaxf(pv, bound);
-    // idx = #{i < n_scales-1 : table[i] < s}   (binary search, table ascending)
-    int lo = 0, hi = n_scales - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (table[mid] < s) lo = mid + 1; else hi = mid;
+// The coder's arrays (scale indexes, symbols) are NCHW rasters -- per image and channel HW consecutive entries -- while the maps they
+// come from / go to are pixel-major ([pixel][channel]).  One thread per (pixel, channel) writing idx[(b z + c) HW + p] scatters single
+// bytes / dwords HW entries apart; since round 5 these arrays may BE the host's pinned buffers (lvae_dec_block / lvae_enc_block with
+// idx_dev / sym_dev = NULL: the kernels write / read host memory over the link, no blit launch and no device copy on the decode
+// chain), where every scattered access would be a bus transaction of its own.  So: a workgroup owns 64 consecutive pixels of one image,
+// works through them pixel-major (coalesced on the map side), transposes 64 pixels x <= 64 channels through LDS and touches the
+// raster in runs of 64 consecutive entries per channel.  Per element the arithmetic is unchanged (same bits).
+constexpr int CT_PIX = 64, CT_CH = 64, CT_LD = CT_PIX + 1;
+
+__global__ __launch_bounds__(256) void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
+                                                          const float* __restrict__ table, int n_scales, float bound, int HW, int z,
+                                                          int* __restrict__ status) {
+    __shared__ int tile[CT_CH * CT_LD];
+    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const long m0 = (long)b * HW + p0;
+    for (int c0 = 0; c0 < z; c0 += CT_CH) {
+        const int zc = (z - c0) < CT_CH ? (z - c0) : CT_CH;
+        for (int i = threadIdx.x; i < np * zc; i += 256) {
+            const int pl = i / zc, c = c0 + (i - pl * zc);
+            const long m = m0 + pl;
+            const float mean = prm[m * 2 * z + c];
+            const float lv = prm[m * 2 * z + z + c];
+            // a NaN / inf prior parameter (an fp16 overflow of the f16x2 arithmetic upstream, include/lvae_hip.h "status word") would become
+            // index 0 / 63 and a NaN mean silently: report it (one atomic per wave that saw one)
+            if (status && !(fabsf(mean) <= 3.4028234664e38f && fabsf(lv) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_PRIOR);
+            // softplus(x + 2.3) - 2.3  (torch: beta=1, threshold=20)
+            const float xs = lv + 2.3f;
+            const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
+            const float pv = expf(sp - 2.3f);
+            const float sc = fmaxf(pv, bound);
+            // idx = #{i < n_scales-1 : table[i] < s}   (binary search, table ascending)
+            int lo = 0, hi = n_scales - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (table[mid] < sc) lo = mid + 1; else hi = mid;
+            }
+            pm[m * z + c] = mean;
+            tile[(c - c0) * CT_LD + pl] = lo;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < zc * CT_PIX; j += 256) {
+            const int cl = j / CT_PIX, pl = j - cl * CT_PIX;
+            if (pl < np) idx[((long)b * z + c0 + cl) * HW + p0 + pl] = (uint8_t)tile[cl * CT_LD + pl];
+        }
+        __syncthreads();
     }
-    pm[e] = mean;
-    const long b = m / HW;
-    const int p = (int)(m - b * HW);
-    idx[(b * z + c) * HW + p] = (uint8_t)lo;
 }
 
-__global__ void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
-                                float* __restrict__ zhat, long total, int HW, int z, int ldz, int* __restrict__ status) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // e = m*ldz + c over the PADDED rows
-    if (e >= total) return;
-    const long m = e / ldz;
-    const int c = (int)(e - m * ldz);
-    if (c >= z) { zhat[e] = 0.f; return; }
-    const float mu = pm[m * z + c];
-    const float r = rintf(qm[m * z + c] - mu);  // v_rndne_f32: round-half-to-even == torch.round
-    if (status && !(fabsf(r) < 2147483648.0f)) atomicOr(status, LVAE_STATUS_NONFINITE_LATENT);      // NaN / inf / no int32 symbol
-    zhat[e] = r + mu;
-    const long b = m / HW;
-    const int p = (int)(m - b * HW);
-    sym[(b * z + c) * HW + p] = (int32_t)r;
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
+                                                       float* __restrict__ zhat, int HW, int z, int ldz, int* __restrict__ status) {
+    __shared__ int tile[CT_CH * CT_LD];
+    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const long m0 = (long)b * HW + p0;
+    for (int c0 = 0; c0 < ldz; c0 += CT_CH) {                        // over the PADDED rows (columns z .. ldz - 1 of zhat are zeroed)
+        const int zc = (ldz - c0) < CT_CH ? (ldz - c0) : CT_CH;
+        for (int i = threadIdx.x; i < np * zc; i += 256) {
+            const int pl = i / zc, c = c0 + (i - pl * zc);
+            const long m = m0 + pl;
+            if (c >= z) { zhat[m * ldz + c] = 0.f; continue; }
+            const float mu = pm[m * z + c];
+            const float r = rintf(qm[m * z + c] - mu);  // v_rndne_f32: round-half-to-even == torch.round
+            if (status && !(fabsf(r) < 2147483648.0f)) atomicOr(status, LVAE_STATUS_NONFINITE_LATENT);      // NaN / inf / no int32 symbol
+            zhat[m * ldz + c] = r + mu;
+            tile[(c - c0) * CT_LD + pl] = (int32_t)r;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < zc * CT_PIX; j += 256) {
+            const int cl = j / CT_PIX, pl = j - cl * CT_PIX;
+            if (pl < np && c0 + cl < z) sym[((long)b * z + c0 + cl) * HW + p0 + pl] = tile[cl * CT_LD + pl];
+        }
+        __syncthreads();
+    }
 }
 
-__global__ void dequantize_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ zhat,
-                                  long total, int HW, int z, int ldz) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const long m = e / ldz;
-    const int c = (int)(e - m * ldz);
-    if (c >= z) { zhat[e] = 0.f; return; }
-    const long b = m / HW;
-    const int p = (int)(m - b * HW);
-    zhat[e] = (float)sym[(b * z + c) * HW + p] + pm[m * z + c];
+__global__ __launch_bounds__(256) void dequantize_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ zhat,
+                                                         int HW, int z, int ldz) {
+    __shared__ int tile[CT_CH * CT_LD];
+    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const long m0 = (long)b * HW + p0;
+    for (int c0 = 0; c0 < ldz; c0 += CT_CH) {
+        const int zc = (ldz - c0) < CT_CH ? (ldz - c0) : CT_CH;
+        for (int j = threadIdx.x; j < zc * CT_PIX; j += 256) {
+            const int cl = j / CT_PIX, pl = j - cl * CT_PIX;
+            if (pl < np && c0 + cl < z) tile[cl * CT_LD + pl] = sym[((long)b * z + c0 + cl) * HW + p0 + pl];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * zc; i += 256) {
+            const int pl = i / zc, c = c0 + (i - pl * zc);
+            const long m = m0 + pl;
+            zhat[m * ldz + c] = c >= z ? 0.f : (float)tile[(c - c0) * CT_LD + pl] + pm[m * z + c];
+        }
+        __syncthreads();
+    }
 }
 
 // Eval-mode rate estimate (qarv/model.py:95-96; CompressAI GaussianConditional._likelihood): per latent element
@@ -652,28 +690,25 @@ extern "C" int lvae_gemv_f32(const float* Wt, const float* b, const float* x, fl
 
 extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
                                     float scale_bound, int B, int HW, int z, int* status, void* stream) {
-    if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || HW <= 0 || z <= 0) return -22;
-    const long total = (long)B * HW * z;
-    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prm, pm,
-                       idx, scale_table, n_scales, scale_bound, total, HW, z, status);
+    if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || B > 65535 || HW <= 0 || z <= 0) return -22;
+    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, pm,
+                       idx, scale_table, n_scales, scale_bound, HW, z, status);
     return (int)hipGetLastError();
 }
 
 extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
                                  int* status, void* stream) {
-    if (!qm || !pm || !sym || !zhat || B <= 0 || HW <= 0 || z <= 0 || ldz < z) return -22;
-    const long total = (long)B * HW * ldz;
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
-                       zhat, total, HW, z, ldz, status);
+    if (!qm || !pm || !sym || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
+                       zhat, HW, z, ldz, status);
     return (int)hipGetLastError();
 }
 
 extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz,
                                    void* stream) {
-    if (!sym || !pm || !zhat || B <= 0 || HW <= 0 || z <= 0 || ldz < z) return -22;
-    const long total = (long)B * HW * ldz;
-    hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym, pm,
-                       zhat, total, HW, z, ldz);
+    if (!sym || !pm || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
+    hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, sym, pm,
+                       zhat, HW, z, ldz);
     return (int)hipGetLastError();
 }
 

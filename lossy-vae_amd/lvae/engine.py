@@ -459,8 +459,9 @@ class Plan:
             seg = self.segments[key] = (arr, len(ops))
         return seg
 
-    def _run_native(self, lo, hi, s):
-        arr, n = self._segment(lo, len(self.ops) if hi is None else hi)
+    def _run_native(self, lo, hi, s, seg=None):
+        """seg = (array, count): a prepared segment of ops lo .. hi (models/base.py: the host-aliased copy of a decode's first segment)."""
+        arr, n = seg if seg is not None else self._segment(lo, len(self.ops) if hi is None else hi)
         bad = ctypes.c_int(-1)
         ss = self.side_stream.cuda_stream if self.side_stream is not None else None
         rc = self.lib.lvae_run_ops(arr, n, ctypes.c_void_p(s), ctypes.c_void_p(ss) if ss is not None else None, ctypes.byref(bad))

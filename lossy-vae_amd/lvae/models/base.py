@@ -247,8 +247,33 @@ class CodecBase(nn.Module):
     status_checks = os.environ.get('LVAE_NO_STATUS_CHECK') != '1'           # A-B switch of tools/ab_status.sh ONLY: '1' = the group loops run
                                                                             # without the status word (what the non-finite guard costs)
 
+    # The coder's arrays travel without copies (round 5): the index / quantize / dequantize launches of a group's native loops are recorded
+    # with the plan's PINNED HOST arrays as their raster operands (device-mapped host memory; the kernels touch the raster in runs of 64
+    # consecutive entries, csrc/pointwise.hip), so a decode has no blit launch between a segment and the coder or between the coder and the
+    # next segment, and an encode none behind its segments.  'both' | 'dec' | 'enc' | 'none' (A-B switch LVAE_ZERO_COPY: tools/r5_zero_copy.sh); the per-block Python loops and the test hooks keep the device arrays.
+    zero_copy_coder_io = os.environ.get('LVAE_ZERO_COPY', 'both')
+
     @staticmethod
-    def _group_blocks(pl, kind, cuts, offs, n):
+    def _alias_host(pl, seg, n_ops):
+        """A copy of a native segment whose launches address pl.sym_host / pl.idx_host wherever the recorded ones address pl.sym_all / pl.idx_all."""
+        from .. import _native
+        raster_ops = {_native.OP_KINDS[k] for k in ('lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32')}
+        spans = [(pl.sym_all.data_ptr(), pl.sym_all.numel() * 4, pl.sym_host.data_ptr()), (pl.idx_all.data_ptr(), pl.idx_all.numel(), pl.idx_host.data_ptr())]
+        out = (_native.Op * max(1, n_ops))()
+        ctypes.memmove(out, seg, ctypes.sizeof(_native.Op) * n_ops)
+        for o in out[:n_ops]:
+            if o.kind not in raster_ops:
+                continue
+            for j in range(len(o.p)):
+                a = o.p[j]
+                if a:
+                    for lo_, size, host in spans:
+                        if lo_ <= a < lo_ + size:
+                            o.p[j] = host + (a - lo_)
+        return out
+
+    @classmethod
+    def _group_blocks(cls_, pl, kind, cuts, offs, n):
         """The plan's latent blocks as a native array, cached on the plan: `cuts` = op index after each block's segment, `offs` = its
         element offset into sym_all / idx_all; per_image from pl.lat_shapes."""
         from .. import _native
@@ -256,6 +281,7 @@ class CodecBase(nn.Module):
         cached = getattr(pl, key, None)
         if cached is None:
             cls = _native.DecBlock if kind == 'dec' else _native.EncBlock
+            zero_copy = cls_.zero_copy_coder_io in (kind, 'both')
             arr = (cls * len(cuts))()
             segs, lo = [], 0
             for li, cut in enumerate(cuts):
@@ -267,8 +293,14 @@ class CodecBase(nn.Module):
                 b.ops, b.n_ops, b.per_image = ctypes.cast(seg, ctypes.c_void_p).value, n_ops, z * hw
                 b.idx_dev, b.idx_host = pl.idx_all.data_ptr() + o, pl.idx_host.data_ptr() + o
                 b.sym_dev, b.sym_host = pl.sym_all.data_ptr() + 4 * o, pl.sym_host.data_ptr() + 4 * o
+                if zero_copy:
+                    seg = cls_._alias_host(pl, seg, n_ops)
+                    segs[-1] = seg
+                    b.ops, b.idx_dev, b.sym_dev = ctypes.cast(seg, ctypes.c_void_p).value, None, None
                 lo = cut
             tail, n_tail = pl._segment(lo, len(pl.ops)) if kind == 'dec' else (None, 0)
+            if zero_copy and n_tail:                       # (the last block's symbols are read by the tail's first launch)
+                tail = cls_._alias_host(pl, tail, n_tail)
             early = None
             if kind == 'dec' and len(cuts):                # the same blocks with block 0's launches taken out: _decode_group_native issues
                 early = (cls * len(cuts))()                # that segment itself, before it looks at the strings
@@ -281,7 +313,7 @@ class CodecBase(nn.Module):
     def _decode_group_native(self, pl, cuts, offs, n, strings, tables, nthreads, stream, T=None):
         """strings[b][li]: image b's stream of latent block li.  Runs the group's whole decode; the caller copies pl.out afterwards."""
         from .. import _native
-        arr, _segs, tail, n_tail, early = self._group_blocks(pl, 'dec', cuts, offs, n)
+        arr, segs, tail, n_tail, early = self._group_blocks(pl, 'dec', cuts, offs, n)
         nb = len(cuts)
         # The first segment (bias -> ... -> prior of the top latent block) does not depend on the bitstream: it is on its way to the GPU
         # before this thread turns to the strings (header parsing, container offsets, pointer tables: ~0.1-0.2 ms of interpreter time
@@ -289,7 +321,7 @@ class CodecBase(nn.Module):
         # so the other group's thread prepares meanwhile.
         if early is not None:
             with torch.cuda.device(pl.device):
-                pl._run_native(0, cuts[0], stream.cuda_stream)
+                pl._run_native(0, cuts[0], stream.cuda_stream, seg=(segs[0], arr[0].n_ops))
             arr = early
         if callable(strings):
             strings = strings()                            # [image][block] -> bytes, or (bytes-like container, offset, length): no copies

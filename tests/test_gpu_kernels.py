@@ -346,6 +346,41 @@ def test_prior_index_quantize_dequantize(L):
     assert sh.flatten().tolist() == [0, 2, 2, 0, -2, -2, 4, 4]
 
 
+@pytest.mark.parametrize('B,HW,z,ldz,pinned', [(2, 200, 96, 96, False), (3, 64, 70, 72, False), (1, 129, 8, 8, True), (2, 96, 130, 132, True)])
+def test_index_quantize_tiles_and_pinned_rasters(L, B, HW, z, ldz, pinned):
+    """The raster-side kernels work on tiles of 64 pixels x 64 channels (csrc/pointwise.hip): several pixel tiles, ragged last tile,
+    more than one channel chunk, padded rows -- and, `pinned`, with the NCHW rasters in pinned HOST memory (what the native group loops
+    hand them: lvae_dec_block.idx_dev = NULL), read back on the host after a synchronisation."""
+    g = torch.Generator().manual_seed(HW + z)
+    M = B * HW
+    prm = (torch.randn(M, 2 * z, generator=g) * 2).cuda()
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).cuda()
+    pm = torch.empty(M, z, device='cuda')
+    raster = (lambda dt: torch.empty(B, z, HW, dtype=dt).pin_memory()) if pinned else (lambda dt: torch.empty(B, z, HW, dtype=dt, device='cuda'))
+    idx, sym = raster(torch.uint8), raster(torch.int32)
+    assert L.lvae_prior_index_f32(prm.data_ptr(), pm.data_ptr(), idx.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, None, _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pm, prm[:, :z])
+    s64 = torch.clamp(torch.exp(F.softplus(prm[:, z:].double() + 2.3) - 2.3), min=float(table[0]))
+    ref = (table.double()[None, None, :63] < s64[..., None]).sum(-1).view(B, HW, z).permute(0, 2, 1)
+    near = ((s64[..., None] / table.double()[None, None, :] - 1).abs().min(-1)[0] < 1e-5).view(B, HW, z).permute(0, 2, 1)
+    assert torch.equal(idx.cuda().long()[~near], ref[~near])
+    qm = (torch.randn(M, z, generator=g) * 6).cuda()
+    zhat = torch.full((M, ldz), float('nan'), device='cuda')
+    assert L.lvae_quantize_f32(qm.data_ptr(), pm.data_ptr(), sym.data_ptr(), zhat.data_ptr(), B, HW, z, ldz, None, _st()) == 0
+    torch.cuda.synchronize()
+    r = torch.round(qm - pm)
+    assert torch.equal(sym.cuda(), r.int().view(B, HW, z).permute(0, 2, 1).contiguous())
+    assert torch.equal(zhat[:, :z], r + pm) and not zhat[:, z:].any()
+    if pinned:                                   # the decode direction: the HOST writes the symbols, the kernel reads them in place
+        sym.copy_(torch.randint(-40, 41, (B, z, HW), generator=g, dtype=torch.int32))
+    z2 = torch.full((M, ldz), float('nan'), device='cuda')
+    assert L.lvae_dequantize_f32(sym.data_ptr(), pm.data_ptr(), z2.data_ptr(), B, HW, z, ldz, _st()) == 0
+    torch.cuda.synchronize()
+    want = sym.cuda().permute(0, 2, 1).reshape(M, z).float() + pm
+    assert torch.equal(z2[:, :z], want) and not z2[:, z:].any()
+
+
 def test_sqerr(L):
     a, b = torch.rand(2, 3 * 70 * 90, device='cuda'), torch.rand(2, 3 * 70 * 90, device='cuda')
     out = torch.zeros(2, dtype=torch.float64, device='cuda')
