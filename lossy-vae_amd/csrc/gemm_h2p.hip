@@ -58,18 +58,29 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // FULL (pre-split output only): quad pairs exchange halves by DPP row shifts so that one lane holds the hi terms of EIGHT consecutive
 // columns (its partner the lo' terms): one 16-B store per lane and 8 rows x 128 B = whole lines per instruction instead of two 8-B
 // stores covering half lines.
-template <int TN, int EPI, bool H2, bool FULL>
+// FOLDED: the tail of the serial split-K form -- `acc` holds the running sum of the slices, and the operations are splitk_epilogue_store's
+// (quad transpose first, then + bias as a 4-column vector, GELU | fma(gamma, v, residual) | + residual): that function loads bias,
+// gamma and residual inside every unit, each load followed by a full wait -- eight units of two dependent memory round trips at the
+// end of launches whose whole K loop is ~10 us (the stride-16 / 32 / 64 MLPs of both paths' dependency chains).
+template <int TN, int EPI, bool H2, bool FULL, bool FOLDED = false>
 __device__ __forceinline__ void h2p_epilogue_fast(const lvae_gemm_desc& d, f32x16 (&acc)[2][TN], int m0, int n0, int rows_a, int wave_m,
                                                   int wave_n, int li, int lh) {
+#pragma clang fp contract(off)
     const int lj = li & 3;
     float cbias[TN], cgam[TN];
+    f32x4 vbias[TN], vgam[TN];
     int c4[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int colb = n0 + (wave_n * TN + b) * 32;
-        cbias[b] = d.bias ? d.bias[colb + li] : 0.f;
-        cgam[b] = EPI == LVAE_EPI_GAMMA_RES ? d.gamma[colb + li] : 1.f;
         c4[b] = colb + (li & ~3);
+        if constexpr (FOLDED) {
+            vbias[b] = *(const f32x4*)(d.bias + c4[b]);
+            if constexpr (EPI == LVAE_EPI_GAMMA_RES) vgam[b] = *(const f32x4*)(d.gamma + c4[b]);
+        } else {
+            cbias[b] = d.bias ? d.bias[colb + li] : 0.f;
+            cgam[b] = EPI == LVAE_EPI_GAMMA_RES ? d.gamma[colb + li] : 1.f;
+        }
     }
     constexpr bool HAS_RES = EPI == LVAE_EPI_GAMMA_RES || EPI == LVAE_EPI_RES;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.out + (long)m0 * d.ldo * 4), 0, rows_a * d.ldo * 4, 0x00020000);
@@ -93,15 +104,30 @@ __device__ __forceinline__ void h2p_epilogue_fast(const lvae_gemm_desc& d, f32x1
             const int rowoff = r * d.ldo * 4;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const lvae_f2 s01 = (lvae_f2){acc[a][b][4 * g + 0], acc[a][b][4 * g + 1]} + (lvae_f2)(cbias[b]);      // (packed adds)
-                const lvae_f2 s23 = (lvae_f2){acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + (lvae_f2)(cbias[b]);
-                float v0 = s01[0], v1 = s01[1], v2 = s23[0], v3 = s23[1];
-                if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
-                else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
-                quad_transpose(v0, v1, v2, v3, lj);
-                if constexpr (HAS_RES) {
-                    const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
-                    v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                float v0, v1, v2, v3;
+                if constexpr (FOLDED) {
+                    v0 = acc[a][b][4 * g + 0]; v1 = acc[a][b][4 * g + 1]; v2 = acc[a][b][4 * g + 2]; v3 = acc[a][b][4 * g + 3];
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    v0 += vbias[b][0]; v1 += vbias[b][1]; v2 += vbias[b][2]; v3 += vbias[b][3];
+                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
+                    if constexpr (HAS_RES) {
+                        const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
+                        if constexpr (EPI == LVAE_EPI_GAMMA_RES) {        // (splitk_epilogue_store's "r + g * v", which hipcc contracts: one rounding)
+                            v0 = __builtin_fmaf(vgam[b][0], v0, r4[0]); v1 = __builtin_fmaf(vgam[b][1], v1, r4[1]);
+                            v2 = __builtin_fmaf(vgam[b][2], v2, r4[2]); v3 = __builtin_fmaf(vgam[b][3], v3, r4[3]);
+                        } else { v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3]; }
+                    }
+                } else {
+                    const lvae_f2 s01 = (lvae_f2){acc[a][b][4 * g + 0], acc[a][b][4 * g + 1]} + (lvae_f2)(cbias[b]);      // (packed adds)
+                    const lvae_f2 s23 = (lvae_f2){acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + (lvae_f2)(cbias[b]);
+                    v0 = s01[0]; v1 = s01[1]; v2 = s23[0]; v3 = s23[1];
+                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
+                    else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    if constexpr (HAS_RES) {
+                        const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
+                        v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
+                    }
                 }
                 if constexpr (H2) {
                     unsigned h0, l0, h1, l1;
@@ -306,6 +332,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing (redundant) DMAs have landed before LDS is reused / freed
     if constexpr (FOLD) {
+#ifndef H2P_EXP_GENERIC_EPI
+        if (d.bias && n0 + BN <= d.N && !((d.ldo | d.ldres) & 3)) {          // uniform: a straight-line form of the tail below
+            if (d.epi == LVAE_EPI_BIAS_GELU && d.out_h2 && !(d.ldo & 31)) {
+                h2p_epilogue_fast<TN, LVAE_EPI_BIAS_GELU, true, H2P_FULL_LINE, true>(d, tot, m0, n0, rows_a, wave_m, wave_n, li, lh);
+                return;
+            }
+            if (d.epi == LVAE_EPI_GAMMA_RES && !d.out_h2) {
+                h2p_epilogue_fast<TN, LVAE_EPI_GAMMA_RES, false, false, true>(d, tot, m0, n0, rows_a, wave_m, wave_n, li, lh);
+                return;
+            }
+            if (d.epi == LVAE_EPI_RES && !d.out_h2) {
+                h2p_epilogue_fast<TN, LVAE_EPI_RES, false, false, true>(d, tot, m0, n0, rows_a, wave_m, wave_n, li, lh);
+                return;
+            }
+        }
+#endif
         // the reduce kernel's tail on this tile: 4 consecutive columns of one row per lane (quad transpose), then its epilogue function
         const int lj = li & 3;
 #pragma unroll

@@ -405,17 +405,18 @@ __global__ void prior_sample_kernel(const float* __restrict__ prm, float* __rest
 // bytes / dwords HW entries apart; since round 5 these arrays may BE the host's pinned buffers (lvae_dec_block / lvae_enc_block with
 // idx_dev / sym_dev = NULL: the kernels write / read host memory over the link, no blit launch and no device copy on the decode
 // chain), where every scattered access would be a bus transaction of its own.  So: a workgroup owns 64 consecutive pixels of one image,
-// works through them pixel-major (coalesced on the map side), transposes 64 pixels x <= 64 channels through LDS and touches the
+// works through them pixel-major (coalesced on the map side), transposes 64 pixels x <= 16 channels (blockIdx.y: the channel chunk) through LDS and touches the
 // raster in runs of 64 consecutive entries per channel.  Per element the arithmetic is unchanged (same bits).
-constexpr int CT_PIX = 64, CT_CH = 64, CT_LD = CT_PIX + 1;
+constexpr int CT_PIX = 64, CT_CH = 16, CT_LD = CT_PIX + 1;      // (16 channels per workgroup: 4 elements per thread -- enough workgroups to fill the chip on the stride-16 maps)
 
 __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
                                                           const float* __restrict__ table, int n_scales, float bound, int HW, int z,
                                                           int* __restrict__ status) {
     __shared__ int tile[CT_CH * CT_LD];
-    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const int b = blockIdx.z, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
     const long m0 = (long)b * HW + p0;
-    for (int c0 = 0; c0 < z; c0 += CT_CH) {
+    {
+        const int c0 = blockIdx.y * CT_CH;
         const int zc = (z - c0) < CT_CH ? (z - c0) : CT_CH;
         for (int i = threadIdx.x; i < np * zc; i += 256) {
             const int pl = i / zc, c = c0 + (i - pl * zc);
@@ -451,9 +452,10 @@ __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restric
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
                                                        float* __restrict__ zhat, int HW, int z, int ldz, int* __restrict__ status) {
     __shared__ int tile[CT_CH * CT_LD];
-    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const int b = blockIdx.z, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
     const long m0 = (long)b * HW + p0;
-    for (int c0 = 0; c0 < ldz; c0 += CT_CH) {                        // over the PADDED rows (columns z .. ldz - 1 of zhat are zeroed)
+    {
+        const int c0 = blockIdx.y * CT_CH;                             // over the PADDED rows (columns z .. ldz - 1 of zhat are zeroed)
         const int zc = (ldz - c0) < CT_CH ? (ldz - c0) : CT_CH;
         for (int i = threadIdx.x; i < np * zc; i += 256) {
             const int pl = i / zc, c = c0 + (i - pl * zc);
@@ -477,9 +479,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void dequantize_kernel(const int32_t* __restrict__ sym, const float* __restrict__ pm, float* __restrict__ zhat,
                                                          int HW, int z, int ldz) {
     __shared__ int tile[CT_CH * CT_LD];
-    const int b = blockIdx.y, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
+    const int b = blockIdx.z, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
     const long m0 = (long)b * HW + p0;
-    for (int c0 = 0; c0 < ldz; c0 += CT_CH) {
+    {
+        const int c0 = blockIdx.y * CT_CH;
         const int zc = (ldz - c0) < CT_CH ? (ldz - c0) : CT_CH;
         for (int j = threadIdx.x; j < zc * CT_PIX; j += 256) {
             const int cl = j / CT_PIX, pl = j - cl * CT_PIX;
@@ -691,7 +694,7 @@ extern "C" int lvae_gemv_f32(const float* Wt, const float* b, const float* x, fl
 extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
                                     float scale_bound, int B, int HW, int z, int* status, void* stream) {
     if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || B > 65535 || HW <= 0 || z <= 0) return -22;
-    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, pm,
+    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((z + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, pm,
                        idx, scale_table, n_scales, scale_bound, HW, z, status);
     return (int)hipGetLastError();
 }
@@ -699,7 +702,7 @@ extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, c
 extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
                                  int* status, void* stream) {
     if (!qm || !pm || !sym || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((ldz + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
                        zhat, HW, z, ldz, status);
     return (int)hipGetLastError();
 }
@@ -707,7 +710,7 @@ extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym,
 extern "C" int lvae_dequantize_f32(const int32_t* sym, const float* pm, float* zhat, int B, int HW, int z, int ldz,
                                    void* stream) {
     if (!sym || !pm || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
-    hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, sym, pm,
+    hipLaunchKernelGGL(dequantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((ldz + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, sym, pm,
                        zhat, HW, z, ldz);
     return (int)hipGetLastError();
 }
