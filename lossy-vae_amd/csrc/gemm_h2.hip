@@ -255,6 +255,8 @@ __global__ __launch_bounds__(256, (TN == 1 ? 3 : 2)) void gemm_h2_kernel(const l
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accH[a][b][r] = __builtin_fmaf(accX[a][b][r], 1.0f / 2048.0f, accH[a][b][r]);
+    // (gemm_common.h's straight-line epilogues were measured here too -- profiles/r05_bench_ab_gemm_h2_straight_line_epilogue.txt: no gain
+    //  on the bench, this kernel's launches are bound by their operand conversion -- and are not taken)
     gemm_finish<C>(d, accH, m0, n0, wave_m, wave_n, li, lh, (void*)smem, t);
 }
 

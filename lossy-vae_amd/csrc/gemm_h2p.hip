@@ -30,9 +30,6 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef H2P_FULL_LINE
-#define H2P_FULL_LINE true
-#endif
 // timing ablations (wrong results by construction; tools/build_exp.sh only): what a launch costs without its MFMAs / fragment reads / epilogue
 #if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2P_EXP_NOMFMA) || defined(H2P_EXP_NODSR) || defined(H2P_EXP_NOEPI) || defined(H2P_EXP_NODMA))
 #error "H2P_EXP_* ablations need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
@@ -48,113 +45,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define H2P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
-// Straight-line epilogue for the launches this kernel exists for (fc1: + bias -> GELU -> pre-split store; fc2: + bias, * gamma,
-// + residual -> fp32 store; both row-major on a full-width tile).  gemm_epilogue decides epi / store / out_h2 / residual at RUN time
-// inside its unit loop: every 4-element unit is a chain of uniform branches, its store sits behind an exec-mask branch, and the
-// compiler can neither interleave the units' dependent FMA chains nor keep more than one store in flight.  Here the case is a
-// template parameter, rows beyond M are dropped by the buffer resource's range check (no branch around any access) and the whole
-// wave tile unrolls.  The operations per element and their order are gemm_epilogue's (acc + bias; GELU | * gamma; quad transpose;
-// + residual; split_pair_h2), hence the same bits (tests/test_gpu_f16x2.py::test_gemm_h2p_equals_h2_bit_for_bit).
-// FULL (pre-split output only): quad pairs exchange halves by DPP row shifts so that one lane holds the hi terms of EIGHT consecutive
-// columns (its partner the lo' terms): one 16-B store per lane and 8 rows x 128 B = whole lines per instruction instead of two 8-B
-// stores covering half lines.
-// FOLDED: the tail of the serial split-K form -- `acc` holds the running sum of the slices, and the operations are splitk_epilogue_store's
-// (quad transpose first, then + bias as a 4-column vector, GELU | fma(gamma, v, residual) | + residual): that function loads bias,
-// gamma and residual inside every unit, each load followed by a full wait -- eight units of two dependent memory round trips at the
-// end of launches whose whole K loop is ~10 us (the stride-16 / 32 / 64 MLPs of both paths' dependency chains).
-template <int TN, int EPI, bool H2, bool FULL, bool FOLDED = false>
-__device__ __forceinline__ void h2p_epilogue_fast(const lvae_gemm_desc& d, f32x16 (&acc)[2][TN], int m0, int n0, int rows_a, int wave_m,
-                                                  int wave_n, int li, int lh) {
-#pragma clang fp contract(off)
-    const int lj = li & 3;
-    float cbias[TN], cgam[TN];
-    f32x4 vbias[TN], vgam[TN];
-    int c4[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int colb = n0 + (wave_n * TN + b) * 32;
-        c4[b] = colb + (li & ~3);
-        if constexpr (FOLDED) {
-            vbias[b] = *(const f32x4*)(d.bias + c4[b]);
-            if constexpr (EPI == LVAE_EPI_GAMMA_RES) vgam[b] = *(const f32x4*)(d.gamma + c4[b]);
-        } else {
-            cbias[b] = d.bias ? d.bias[colb + li] : 0.f;
-            cgam[b] = EPI == LVAE_EPI_GAMMA_RES ? d.gamma[colb + li] : 1.f;
-        }
-    }
-    constexpr bool HAS_RES = EPI == LVAE_EPI_GAMMA_RES || EPI == LVAE_EPI_RES;
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.out + (long)m0 * d.ldo * 4), 0, rows_a * d.ldo * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? (const char*)d.res + (long)m0 * d.ldres * 4 : (const char*)d.out), 0, HAS_RES ? rows_a * d.ldres * 4 : 0, 0x00020000);
-    const bool odd_quad = (li & 4) != 0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        u32x4_t rv[4][TN];
-        if constexpr (HAS_RES) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
-#pragma unroll
-                for (int b = 0; b < TN; ++b) rv[g][b] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (r * d.ldres + c4[b]) * 4, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;          // tile-local row this lane stores
-            const int rowoff = r * d.ldo * 4;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                float v0, v1, v2, v3;
-                if constexpr (FOLDED) {
-                    v0 = acc[a][b][4 * g + 0]; v1 = acc[a][b][4 * g + 1]; v2 = acc[a][b][4 * g + 2]; v3 = acc[a][b][4 * g + 3];
-                    quad_transpose(v0, v1, v2, v3, lj);
-                    v0 += vbias[b][0]; v1 += vbias[b][1]; v2 += vbias[b][2]; v3 += vbias[b][3];
-                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
-                    if constexpr (HAS_RES) {
-                        const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
-                        if constexpr (EPI == LVAE_EPI_GAMMA_RES) {        // (splitk_epilogue_store's "r + g * v", which hipcc contracts: one rounding)
-                            v0 = __builtin_fmaf(vgam[b][0], v0, r4[0]); v1 = __builtin_fmaf(vgam[b][1], v1, r4[1]);
-                            v2 = __builtin_fmaf(vgam[b][2], v2, r4[2]); v3 = __builtin_fmaf(vgam[b][3], v3, r4[3]);
-                        } else { v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3]; }
-                    }
-                } else {
-                    const lvae_f2 s01 = (lvae_f2){acc[a][b][4 * g + 0], acc[a][b][4 * g + 1]} + (lvae_f2)(cbias[b]);      // (packed adds)
-                    const lvae_f2 s23 = (lvae_f2){acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + (lvae_f2)(cbias[b]);
-                    v0 = s01[0]; v1 = s01[1]; v2 = s23[0]; v3 = s23[1];
-                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
-                    else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
-                    quad_transpose(v0, v1, v2, v3, lj);
-                    if constexpr (HAS_RES) {
-                        const f32x4 r4 = __builtin_bit_cast(f32x4, rv[g][b]);
-                        v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
-                    }
-                }
-                if constexpr (H2) {
-                    unsigned h0, l0, h1, l1;
-                    split_pair_h2(v0, v1, h0, l0);
-                    split_pair_h2(v2, v3, h1, l1);
-                    if constexpr (FULL) {
-                        // even quad: {own hi, partner's hi} = hi of columns c8 .. c8 + 7; odd quad: {partner's lo', own lo'}
-                        const unsigned o2 = __builtin_amdgcn_update_dpp(l0, h0, 0x104, 0xF, 0x5, false);     // row_shl:4 into banks 0, 2
-                        const unsigned o3 = __builtin_amdgcn_update_dpp(l1, h1, 0x104, 0xF, 0x5, false);
-                        const unsigned o0 = __builtin_amdgcn_update_dpp(h0, l0, 0x114, 0xF, 0xA, false);     // row_shr:4 into banks 1, 3
-                        const unsigned o1 = __builtin_amdgcn_update_dpp(h1, l1, 0x114, 0xF, 0xA, false);
-                        const int c8 = c4[b] & ~7;
-                        const int off = rowoff + ((c8 >> 5) << 7) + ((c8 & 31) << 1) + (odd_quad ? 64 : 0);
-                        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){o0, o1, o2, o3}, rsO, off, 0, 0);
-                    } else {
-                        const int off = rowoff + ((c4[b] >> 5) << 7) + ((c4[b] & 31) << 1);
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, rsO, off, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){l0, l1}, rsO, off + 64, 0, 0);
-                    }
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){v0, v1, v2, v3}), rsO, rowoff + c4[b] * 4, 0, 0);
-                }
-            }
-        }
-    }
-}
-
+// (the straight-line epilogue h2p_epilogue_fast lives in gemm_common.h)
 // FOLD ("serial split-K", d.ksplit = S > 1 with a_h2): ONE workgroup walks the S contiguous K slices of its tile and adds their partial sums
 // in slice order -- tot = P_0; tot += P_1; ... with P_s = accH_s + accX_s / 2048 -- then applies splitk_epilogue_store: the operations
 // of the parallel form (gemm_h2_kernel with gridDim.y = S + the reduce kernel / last arriver) in the same order, hence the same bits,
