@@ -413,6 +413,9 @@ __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restric
                                                           const float* __restrict__ table, int n_scales, float bound, int HW, int z,
                                                           int* __restrict__ status) {
     __shared__ int tile[CT_CH * CT_LD];
+    __shared__ float tab[256];                         // the scale table (n_scales <= 256: checked by the launcher): the binary search below is
+    if ((int)threadIdx.x < n_scales) tab[threadIdx.x] = table[threadIdx.x];     // six DEPENDENT loads per element -- from LDS, not from L2
+    __syncthreads();
     const int b = blockIdx.z, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
     const long m0 = (long)b * HW + p0;
     {
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restric
             int lo = 0, hi = n_scales - 1;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (table[mid] < sc) lo = mid + 1; else hi = mid;
+                if (tab[mid] < sc) lo = mid + 1; else hi = mid;
             }
             pm[m * z + c] = mean;
             tile[(c - c0) * CT_LD + pl] = lo;
@@ -819,5 +822,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 20; }
+extern "C" int lvae_abi_version(void) { return 21; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 
