@@ -47,6 +47,137 @@ __device__ __forceinline__ float q8_gelu(float x) {
     return 0.5f * x * (1.0f + copysignf(fmaf(-p, e, 1.0f), z));
 }
 
+// Straight-line epilogue per case on a full-width tile (round 5; the recipe of gemm_common.h::h2p_epilogue_fast -- this mode is
+// HBM-bound by construction, and the run-time case analysis below stored 4 bytes (re-quantised output) or 8 bytes (bf16 output) per lane
+// behind an exec-mask branch per unit).  The case is a template parameter, rows >= M are dropped by the buffer descriptors' range
+// check, and the stores are 16 B per lane:
+//   Q8OUT: the four e4m3 dwords of a lane (rows 8 g + ., g = 0 .. 3, the same 4 columns) go through a 4 x 4 transpose ACROSS THE FOUR
+//     QUADS of a 16-lane row (DPP row_shl / row_shr : 4 and : 8 with bank masks -- the quads are the DPP banks, no selects needed): the
+//     lane of bank k then holds 16 consecutive columns of row 8 k + . : one store instead of four;
+//   bf16: quad pairs exchange halves so that even quads hold 8 columns of row g and odd quads 8 columns of row g + 1.
+// Per element the operations are the generic epilogue's (it stays below for ragged tiles): same values.
+template <int TN, int EPI, bool Q8OUT>
+__device__ __forceinline__ void q8_epilogue_fast(const lvae_gemm_desc& d, f32x16 (&acc)[2][TN], int m0, int n0, int rows_a, int wave_m, int wave_n,
+                                                 int li, int lh) {
+    const int lj = li & 3, bank = (li >> 2) & 3;
+    constexpr bool HAS_RES = EPI == LVAE_EPI_GAMMA_RES || EPI == LVAE_EPI_RES;
+    const int N = d.N, M = d.M;
+    char* const outb = (char*)d.out;
+    float cbias[TN], cgam[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wave_n * TN + b) * 32 + li;
+        cbias[b] = d.bias ? d.bias[col] : 0.f;
+        cgam[b] = EPI == LVAE_EPI_GAMMA_RES ? d.gamma[col] : 1.f;
+    }
+    if constexpr (Q8OUT) {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(outb + (long)m0 * N), 0, rows_a * N, 0x00020000);
+        // scale plane of this wave's 64-column block(s): [N / 64][M][2] bytes behind the data
+        const int blk64 = (n0 + wave_n * TN * 32) >> 6;
+        const __amdgpu_buffer_rsrc_t rsS =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(outb + (long)M * N + ((long)blk64 * M + m0) * 2), 0, rows_a * 2, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            unsigned w[TN][4], ebs[TN][4];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
+                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
+                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) { v0 = q8_gelu(v0); v1 = q8_gelu(v1); v2 = q8_gelu(v2); v3 = q8_gelu(v3); }
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+                    am = fmaxf(am, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(am), (4 << 10) | 0x1f)));
+                    am = fmaxf(am, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(am), (8 << 10) | 0x1f)));
+                    am = fmaxf(am, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(am), (16 << 10) | 0x1f)));
+                    const unsigned ab = __float_as_uint(am);
+                    int eb = (int)((ab >> 23) & 0xffu) - 8;                   // the block-scale rule of gemm_lp.hip::lp_quant8 / pack_mxfp8
+                    if ((ab & 0x7fffffu) > 0x600000u) eb += 1;
+                    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+                    const float inv = __uint_as_float((unsigned)(254 - eb) << 23);
+                    int ww = 0;
+                    ww = __builtin_amdgcn_cvt_pk_fp8_f32(v0 * inv, v1 * inv, ww, false);
+                    ww = __builtin_amdgcn_cvt_pk_fp8_f32(v2 * inv, v3 * inv, ww, true);
+                    w[b][g] = (unsigned)ww;
+                    ebs[b][g] = (unsigned)eb;
+                }
+            }
+            // scales: one byte per row and 32-column block, written by the lanes of quad 0 (every lane of a row holds the block's value)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
+                if (li < 4) {
+                    if constexpr (TN == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(ebs[0][g] | (ebs[1][g] << 8)), rsS, r * 2, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)ebs[0][g], rsS, r * 2 + (wave_n & 1), 0, 0);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                // 4 x 4 transpose across the banks: afterwards the lane of bank k holds, in o0 .. o3, the dwords the banks 0 .. 3 held in w[k]
+                unsigned x0 = w[b][0], x1 = w[b][1], x2 = w[b][2], x3 = w[b][3];
+                const unsigned y1 = __builtin_amdgcn_update_dpp(x1, x0, 0x104, 0xF, 0x5, false);     // even banks: w1 <- (bank + 1).w0
+                const unsigned y0 = __builtin_amdgcn_update_dpp(x0, x1, 0x114, 0xF, 0xA, false);     // odd banks:  w0 <- (bank - 1).w1
+                const unsigned y3 = __builtin_amdgcn_update_dpp(x3, x2, 0x104, 0xF, 0x5, false);
+                const unsigned y2 = __builtin_amdgcn_update_dpp(x2, x3, 0x114, 0xF, 0xA, false);
+                const unsigned o2 = __builtin_amdgcn_update_dpp(y2, y0, 0x108, 0xF, 0x3, false);     // banks 0, 1: w2 <- (bank + 2).w0
+                const unsigned o0 = __builtin_amdgcn_update_dpp(y0, y2, 0x118, 0xF, 0xC, false);     // banks 2, 3: w0 <- (bank - 2).w2
+                const unsigned o3 = __builtin_amdgcn_update_dpp(y3, y1, 0x108, 0xF, 0x3, false);
+                const unsigned o1 = __builtin_amdgcn_update_dpp(y1, y3, 0x118, 0xF, 0xC, false);
+                const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * bank + lj;
+                const int col = n0 + (wave_n * TN + b) * 32 + (li & 16);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){o0, o1, o2, o3}, rsO, r * N + col, 0, 0);
+            }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(outb + (long)m0 * d.ldo * 2), 0, rows_a * d.ldo * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(HAS_RES ? (const char*)d.res + (long)m0 * d.ldres * 2 : (const char*)d.out), 0, HAS_RES ? rows_a * d.ldres * 2 : 0, 0x00020000);
+        const bool odd_bank = (bank & 1) != 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            u32x2_t rv[4][TN];
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * g + lj;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        rv[g][b] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsR, (r * d.ldres + n0 + (wave_n * TN + b) * 32 + (li & ~3)) * 2, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                u32x2_t q[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v0 = acc[a][b][4 * g + 0] + cbias[b], v1 = acc[a][b][4 * g + 1] + cbias[b];
+                    float v2 = acc[a][b][4 * g + 2] + cbias[b], v3 = acc[a][b][4 * g + 3] + cbias[b];
+                    if constexpr (EPI == LVAE_EPI_BIAS_GELU) { v0 = q8_gelu(v0); v1 = q8_gelu(v1); v2 = q8_gelu(v2); v3 = q8_gelu(v3); }
+                    else if constexpr (EPI == LVAE_EPI_GAMMA_RES) { v0 *= cgam[b]; v1 *= cgam[b]; v2 *= cgam[b]; v3 *= cgam[b]; }
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    if constexpr (HAS_RES) {
+                        v0 += q8_bf16_lo(rv[g][b][0]); v1 += q8_bf16_hi(rv[g][b][0]); v2 += q8_bf16_lo(rv[g][b][1]); v3 += q8_bf16_hi(rv[g][b][1]);
+                    }
+                    q[g] = (u32x2_t){(unsigned)q8_f32_to_bf16(v0) | ((unsigned)q8_f32_to_bf16(v1) << 16),
+                                     (unsigned)q8_f32_to_bf16(v2) | ((unsigned)q8_f32_to_bf16(v3) << 16)};
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    // even banks: {own, partner's} columns of row g; odd banks: {partner's, own} columns of row g + 1
+                    const unsigned o2 = __builtin_amdgcn_update_dpp(q[g + 1][0], q[g][0], 0x104, 0xF, 0x5, false);
+                    const unsigned o3 = __builtin_amdgcn_update_dpp(q[g + 1][1], q[g][1], 0x104, 0xF, 0x5, false);
+                    const unsigned o0 = __builtin_amdgcn_update_dpp(q[g][0], q[g + 1][0], 0x114, 0xF, 0xA, false);
+                    const unsigned o1 = __builtin_amdgcn_update_dpp(q[g][1], q[g + 1][1], 0x114, 0xF, 0xA, false);
+                    const int r = (wave_m * 2 + a) * 32 + 4 * lh + 8 * (g + (odd_bank ? 1 : 0)) + lj;
+                    const int col = n0 + (wave_n * TN + b) * 32 + (li & ~7);
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){o0, o1, o2, o3}, rsO, (r * d.ldo + col) * 2, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 template <int WM, int TN, int NBUF>
 __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_q8_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles) {
     constexpr int BM = 64 * WM, BN = 64 * TN, ROWS = BM + BN, DATA = ROWS * 64, STAGE = DATA + 2048;     // + A scales (1 KB) + W scales (1 KB)
@@ -180,6 +311,17 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : 2)) void gemm_q8_kernel(co
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Per-column ops, DPP
     // quad transpose (the lane then owns 4 consecutive COLUMNS of one row), then: out_h2 = the result re-quantised to Q8 for the next GEMM
     // (block amax over the 8 lanes that share a row and a 32-column block: ds_swizzle xor 4 / 8 / 16), else bf16 rows.
+#ifndef Q8_EXP_GENERIC_EPI
+    if (n0 + BN <= d.N) {                                                   // uniform: full-width tile -> a straight-line form
+        if (d.out_h2) {
+            if (d.epi == LVAE_EPI_BIAS_GELU) { q8_epilogue_fast<TN, LVAE_EPI_BIAS_GELU, true>(d, acc, m0, n0, rows_a, wave_m, wave_n, li, lh); return; }
+            if (d.epi == LVAE_EPI_BIAS) { q8_epilogue_fast<TN, LVAE_EPI_BIAS, true>(d, acc, m0, n0, rows_a, wave_m, wave_n, li, lh); return; }
+        } else if (!((d.ldo | d.ldres) & 7)) {
+            if (d.epi == LVAE_EPI_GAMMA_RES) { q8_epilogue_fast<TN, LVAE_EPI_GAMMA_RES, false>(d, acc, m0, n0, rows_a, wave_m, wave_n, li, lh); return; }
+            if (d.epi == LVAE_EPI_RES) { q8_epilogue_fast<TN, LVAE_EPI_RES, false>(d, acc, m0, n0, rows_a, wave_m, wave_n, li, lh); return; }
+        }
+    }
+#endif
     const int epi = d.epi, lj = li & 3;
     const bool has_res = epi == LVAE_EPI_GAMMA_RES || epi == LVAE_EPI_RES;
     char* const outb = (char*)d.out;
