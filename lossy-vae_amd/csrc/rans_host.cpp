@@ -258,21 +258,31 @@ extern "C" int lvae_rans_enc_step_selftest(uint64_t x, uint32_t start, uint32_t 
     return (w1.ptr == w2.ptr) ? 0 : 1;
 }
 
-// Per-row decode tables, built lazily for the rows a stream touches (1.25 KB per row):
-//   lut[row][b] = largest s with cdf[s] <= (b << 8)                       (256 buckets of 256 counts)
-//   ent[row][b] = cdf[s] | freq(s) << 16  if the whole bucket lies inside symbol s ("pure"), else 0
+// Per-row decode tables, built lazily for the rows a stream touches (1.3 KB per row):
+//   lut[row][b]   = largest s with cdf[s] <= (b << 8)                     (256 buckets of 256 counts)
+//   freq[row][b], start[row][b] = freq(s), cdf[s]  if the whole bucket lies inside symbol s ("pure"), else freq = 0
+//   info[row]     = the row's MOST PROBABLE symbol (start, freq, id) -- the escape symbol excluded -- and its escape id
 // The serial dependency of a rANS stream is  state -> cf -> symbol -> (start, freq) -> state.  Upstream's linear find_if, and
 // the first form here (bucket -> forward scan of data-dependent length -> two cdf loads), put dependent loads and a poorly
-// predictable branch into that chain for every symbol.  Most of a stream's probability mass sits in symbols much wider than a
-// bucket, so for most symbols ONE load (ent) now yields start and freq and the symbol id comes off the critical path; only
-// buckets that contain a boundary take the scan.  Measured: tools/rans_bench.py.
+// predictable branch into that chain for every symbol.  Three forms, fastest first:
+//   1. most-probable-symbol path (round 5): start and freq of the row's mode depend on the scale index alone, i.e. they are known
+//      BEFORE the state is; if cf falls inside the mode -- a compare the branch predictor learns on compressible data: by definition
+//      the mode is what a stream mostly holds -- the state update is  shift -> multiply -> add  with no table load in the chain
+//      (~5 cycles instead of ~11).  A stream whose symbols are not mostly modes (hit rate below ~80 % over 1024 symbols: each miss is a
+//      mispredicted branch) turns the path off for a while and probes again later; the decoded symbols never depend on that.
+//   2. pure bucket: most of a row's probability mass sits in symbols much wider than a bucket, so ONE pair of loads (freq, start:
+//      two 16-bit tables, no unpacking shift in the chain) yields the update and the symbol id comes off the critical path;
+//   3. only buckets that contain a boundary take the scan.
+// Measured: tools/rans_bench.py, profiles/r05_rans_mps_path.txt.
 // A table set belongs to ONE (qcdf, cdf_len) pair whose contents do not change while it lives.  It may be shared: by the streams of a
 // batch call (decoded concurrently: a row is built by whoever needs it first, the others wait the fraction of a microsecond that takes)
 // and by the nine per-block calls of a decode (lvae_decode_blocks) -- building the ~64 rows costs 25-35 us, which used to sit on the
 // decode chain once per latent block and stream.
-struct RowTab { uint32_t ent[256]; uint8_t lut[256]; };
+struct RowTab { uint16_t freq[256]; uint16_t start[256]; uint8_t lut[256]; };
+struct RowInfo { uint32_t mfreq, mstart; int32_t msym, max_value; };       // mfreq = 0: the row has no most-probable-symbol path
 struct LvaeDecTabs {
     RowTab tabs[256];
+    RowInfo info[256];
     std::atomic<uint8_t> state[256];          // 0 = empty, 1 = being built, 2 = ready, 3 = invalid cdf length
     LvaeDecTabs() { for (auto& st : state) st.store(0, std::memory_order_relaxed); }
 };
@@ -301,12 +311,29 @@ inline bool ensure_row(LvaeDecTabs& D, int row, const int32_t* cdf, int32_t size
         const uint32_t v = (uint32_t)b << 8;
         while (sidx + 1 < size - 1 && (uint32_t)cdf[sidx + 1] <= v) ++sidx;
         T.lut[b] = (uint8_t)sidx;
-        const bool pure = (uint32_t)cdf[sidx + 1] >= v + 256;       // the next boundary is beyond the bucket
-        T.ent[b] = pure ? ((uint32_t)cdf[sidx] | ((uint32_t)(cdf[sidx + 1] - cdf[sidx]) << 16)) : 0u;
+        const uint32_t f = (uint32_t)(cdf[sidx + 1] - cdf[sidx]);
+        // pure: the next boundary is beyond the bucket (f >= 256 then; f <= 65535 for a row of two symbols or more -- a one-symbol
+        // row is all escape symbol and takes the scan)
+        const bool pure = (uint32_t)cdf[sidx + 1] >= v + 256 && f <= 0xFFFFu;
+        T.freq[b] = pure ? (uint16_t)f : (uint16_t)0;
+        T.start[b] = pure ? (uint16_t)cdf[sidx] : (uint16_t)0;
+    }
+    // the most probable symbol among the table's own symbols 0 .. size - 3 (symbol size - 2 = max_value is the escape)
+    RowInfo& R = D.info[row];
+    R.max_value = size - 2;
+    R.mfreq = 0; R.mstart = 0; R.msym = 0;
+    for (int32_t s = 0; s < size - 2; ++s) {
+        const uint32_t f = (uint32_t)(cdf[s + 1] - cdf[s]);
+        if (cdf[s] >= 0 && cdf[s + 1] <= 65536 && cdf[s + 1] > cdf[s] && f > R.mfreq) { R.mfreq = f; R.mstart = (uint32_t)cdf[s]; R.msym = s; }
     }
     D.state[row].store(2, std::memory_order_release);
     return true;
 }
+
+constexpr size_t kMpsWindow = 1024;           // symbols between two looks at the most-probable-symbol path's hit rate
+constexpr uint32_t kMpsMaxMiss = 200;         // misses per window above which the path is switched off (a miss = a mispredicted branch)
+constexpr int kMpsCoolWindows = 8;            // ... for this many windows, then probed again; doubled (up to kMpsCoolMax) every time a probe fails
+constexpr int kMpsCoolMax = 512;
 
 int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n, const int32_t* qcdf, int row_stride,
                   const int32_t* cdf_len, const int32_t* offset, int32_t* sym_out, LvaeDecTabs& D) {
@@ -321,22 +348,46 @@ int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n
     ptr += 2;
     bool overrun = false;
     bool mine[256] = {false};                 // rows this stream has already seen ready (skips the atomic load in the symbol loop)
+    bool use_mps = true;
+    uint32_t miss = 0;
+    int cool = 0, cool_len = kMpsCoolWindows;
+    size_t next_look = kMpsWindow;
     for (size_t i = 0; i < n; ++i) {
         const int32_t row_i = idx[i];
-        const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
-        const int32_t max_value = cdf_len[row_i] - 2;
         if (!mine[row_i]) {
-            if (!ensure_row(D, row_i, cdf, cdf_len[row_i])) return -4;
+            if (!ensure_row(D, row_i, qcdf + (size_t)row_i * row_stride, cdf_len[row_i])) return -4;
             mine[row_i] = true;
         }
-        const RowTab& T = D.tabs[row_i];
+        if (i == next_look) {
+            if (use_mps) {
+                if (miss > kMpsMaxMiss) { use_mps = false; cool = cool_len; cool_len = cool_len * 2 < kMpsCoolMax ? cool_len * 2 : kMpsCoolMax; }
+                else cool_len = kMpsCoolWindows;
+            } else if (--cool <= 0) use_mps = true;
+            miss = 0;
+            next_look += kMpsWindow;
+        }
+        const RowInfo& R = D.info[row_i];
         const uint32_t cf = (uint32_t)(x & 0xFFFF);
-        const uint32_t e = T.ent[cf >> 8];
+        const uint32_t dm = cf - R.mstart;
+        if (__builtin_expect(use_mps && dm < R.mfreq, 1)) {
+            // the row's mode: start / freq came from the scale index, nothing in the chain but shift, multiply, add
+            x = (uint64_t)R.mfreq * (x >> kPrecision) + dm;
+            if (x < kRansL) {
+                uint32_t wv = 0;
+                if (ptr < end) wv = *ptr; else overrun = true;
+                ++ptr;
+                x = (x << 32) | wv;
+                if (overrun) return -3;
+            }
+            sym_out[i] = R.msym + offset[row_i];
+            continue;
+        }
+        ++miss;
+        const int32_t* cdf = qcdf + (size_t)row_i * row_stride;
+        const RowTab& T = D.tabs[row_i];
+        uint32_t freq = T.freq[cf >> 8], start = T.start[cf >> 8];
         int32_t s = T.lut[cf >> 8];
-        uint32_t start, freq;
-        if (__builtin_expect(e != 0, 1)) {
-            start = e & 0xFFFFu; freq = e >> 16;
-        } else {
+        if (__builtin_expect(freq == 0, 0)) {
             while ((uint32_t)cdf[s + 1] <= cf) ++s;      // cdf[size-1] = 65536 > cf terminates the scan
             start = (uint32_t)cdf[s]; freq = (uint32_t)(cdf[s + 1] - cdf[s]);
         }
@@ -348,7 +399,7 @@ int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n
             x = (x << 32) | wv;
         }
         int32_t value = s;
-        if (value == max_value) {
+        if (value == R.max_value) {
             int32_t val = (int32_t)dec_get_bits(x, ptr, end, overrun);
             int32_t n_bypass = val;
             while (val == kMaxBypassVal) {
@@ -363,7 +414,7 @@ int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n
             }
             value = (int32_t)(raw >> 1);
             if (raw & 1) value = -value - 1;
-            else value += max_value;
+            else value += R.max_value;
         }
         sym_out[i] = value + offset[row_i];
         if (overrun) return -3;
@@ -413,6 +464,7 @@ public:
         for (int i = 0; i < need; ++i) cv_.notify_one();          // (notify_all woke all 64 workers for a 4-stream job)
     }
     int size() const { return (int)th_.size(); }
+    void hot(int delta) { hot_.fetch_add(delta, std::memory_order_relaxed); }
 private:
     Pool() {
         int n = (int)std::thread::hardware_concurrency();
@@ -430,8 +482,12 @@ private:
         for (;;) {
             std::shared_ptr<Job> j;
             if (spinner) {
+                // (while a decode loop is running -- hot_ > 0 -- the spinners do not give up after ~0.5 ms: the GPU segments between two
+                //  coder calls of the stride-8 / 16 blocks take 0.3-0.6 ms, so every such block used to find its helpers asleep and paid
+                //  their futex wake-up on the decode chain; bounded all the same, a caller that never leaves cannot pin them for good)
                 const unsigned seen = epoch_.load(std::memory_order_acquire);
-                for (int it = 0; it < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++it) cpu_relax();
+                for (int it = 0; epoch_.load(std::memory_order_acquire) == seen && (it < 20000 || (it < 2000000 && hot_.load(std::memory_order_relaxed) > 0)); ++it)
+                    cpu_relax();
             }
             {
                 std::unique_lock<std::mutex> l(m_);
@@ -460,6 +516,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::atomic<unsigned> epoch_{0};
+    std::atomic<int> hot_{0};                   // decode loops in flight (lvae_coder_pool_hot)
     std::deque<std::shared_ptr<Job>> q_;
     std::vector<std::thread> th_;
 };
@@ -554,6 +611,10 @@ int lvae_rans_encode_batch_end(LvaeEncJob* e) {
     delete e;
     return rc;
 }
+
+// plan_runtime.cpp brackets a pipeline group's decode loop with (+1, -1): the pool's spinning workers then stay awake between the
+// loop's per-block coder calls (Pool::loop)
+void lvae_coder_pool_hot(int delta) { Pool::get().hot(delta); }
 
 // lvae_rans_decode_batch with caller-owned decode tables (plan_runtime.cpp: one table set for the nine per-block calls of a decode);
 // the tables must have been made for this (qcdf, cdf_len) by lvae_dec_tabs_new and die with lvae_dec_tabs_free

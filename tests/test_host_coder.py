@@ -239,3 +239,74 @@ def test_reciprocal_encoder_equals_division_form(L):
         for x in xs:
             if (1 << 31) <= x < (1 << 63):
                 check(x, int(g.integers(0, 65536 - freq + 1)), freq)
+
+
+def _oracle_dec(s, idx, cdf, ln, off):
+    return np.asarray(cs.RansDecoder().decode_with_indexes(s, idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist()), dtype=np.int32)
+
+
+def test_most_probable_symbol_path_on_off_and_switching(L, tabs):
+    """csrc/rans_host.cpp::decode_stream takes the row's most probable symbol without a table load when the state falls inside it,
+    and switches that path off (and probes again, with back-off) on streams that are not mostly modes.  One stream that goes
+    compressible -> noise -> compressible -> escapes -> compressible over many 1024-symbol windows crosses every state of that
+    switch; the decoded symbols must be the oracle decoder's whatever the path did."""
+    cdf, ln, off, dg = tabs
+    g = np.random.default_rng(77)
+    sc = dg.scale_table.numpy()
+    parts = []
+    for kind, n in (('zeros', 5000), ('noise', 23000), ('zeros', 9000), ('escapes', 7000), ('peaked', 30000), ('noise', 3000), ('zeros', 2049)):
+        idx = g.integers(0, 64, size=n).astype(np.uint8)
+        if kind == 'zeros':
+            sym = np.zeros(n, np.int32)
+        elif kind == 'peaked':                         # ~95 % modes
+            sym = np.where(g.random(n) < 0.95, 0, np.rint(g.normal(0, 1, n) * sc[idx])).astype(np.int32)
+        elif kind == 'noise':
+            sym = np.rint(g.normal(0, 1, n) * sc[idx] * 1.5).astype(np.int32)
+        else:
+            sym = np.rint(g.normal(0, 1, n) * sc[idx] * 60.0).astype(np.int32)
+        parts.append((idx, sym))
+    idx = np.concatenate([p[0] for p in parts]); sym = np.concatenate([p[1] for p in parts])
+    s = _enc(L, sym, idx, tabs)
+    rc, out = _dec(L, s, idx, tabs)
+    assert rc == 0 and np.array_equal(out, sym)
+    assert np.array_equal(_oracle_dec(s, idx, cdf, ln, off), sym)
+    # a truncated stream still fails cleanly on the fast path (all modes: every symbol takes it)
+    idx0 = np.full(40000, 30, np.uint8); sym0 = np.zeros(40000, np.int32)
+    s0 = _enc(L, sym0, idx0, tabs)
+    rc, _ = _dec(L, s0[:len(s0) // 2 // 4 * 4], idx0, tabs)
+    assert rc != 0
+
+
+def test_most_probable_symbol_path_on_odd_tables(L):
+    """Rows the Gaussian tables never produce: the mode at the table's first / last own symbol, a row of one own symbol, an escape of frequency 1, a mode of frequency 65535, equal frequencies (first one wins: any choice decodes the same)."""
+    rows = [
+        [0, 60000, 62000, 65000, 65536],               # mode first, 3 own symbols + escape
+        [0, 100, 1000, 65000, 65536],                  # mode last own symbol
+        [0, 65535, 65536],                             # one own symbol of frequency 65535 + escape
+        [0, 32768, 65535, 65536],                      # two own symbols, an escape of frequency 1
+        [0, 16384, 32768, 49152, 65536],               # flat
+        [0, 1, 2, 3, 65533, 65534, 65535, 65536],      # narrow tails around a huge mode
+    ]
+    stride = 16
+    cdf = np.zeros((len(rows), stride), np.int32)
+    ln = np.zeros(len(rows), np.int32)
+    for r, row in enumerate(rows):
+        cdf[r, :len(row)] = row; ln[r] = len(row)
+    off = np.array([0, -1, 0, 0, -2, -3], np.int32)
+    g = np.random.default_rng(5)
+    n = 20000
+    idx = g.integers(0, len(rows), size=n).astype(np.uint8)
+    own = ln[idx] - 2                                   # own symbols per row (the escape excluded)
+    inside = g.random(n) < 0.9
+    k = (g.random(n) * np.maximum(own, 1)).astype(np.int32)
+    sym = np.where(inside & (own > 0), k + off[idx], g.integers(-40, 40, size=n)).astype(np.int32)
+    out = np.empty(8 * n + 64, dtype=np.uint8)
+    nb = L.lvae_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, n, cdf.ctypes.data, stride, ln.ctypes.data, off.ctypes.data, out.ctypes.data, out.size)
+    assert nb >= 8
+    s = out[:nb].tobytes()
+    assert s == cs.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist())
+    dec = np.empty(n, np.int32)
+    buf = np.frombuffer(s, dtype=np.uint8)
+    rc = L.lvae_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, n, cdf.ctypes.data, stride, ln.ctypes.data, off.ctypes.data, dec.ctypes.data)
+    assert rc == 0 and np.array_equal(dec, sym)
+    assert np.array_equal(_oracle_dec(s, idx, cdf, ln, off), sym)

@@ -11,6 +11,10 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
+if os.environ.get('LVAE_LIB'):            # A/B against another build of the native library (tools/r5_rans_mps.sh)
+    from lvae import _native
+    _native.LIB_PATH = os.path.abspath(os.environ['LVAE_LIB'])
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device('cuda', 0)
