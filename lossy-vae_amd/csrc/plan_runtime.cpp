@@ -100,9 +100,6 @@ LvaeEncJob* lvae_rans_encode_batch_begin(int n_streams, const int32_t* const* sy
                                          uint8_t* const* out, const size_t* out_cap, long* out_len, int n_threads);
 int lvae_rans_encode_batch_end(LvaeEncJob* e);
 
-// rans_host.cpp: +1 / -1 around a decode loop -- the coder pool's spinning workers stay awake between its per-block calls
-void lvae_coder_pool_hot(int delta);
-
 namespace {
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
@@ -122,7 +119,6 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
     std::vector<int> status(n_images);
     struct TabsGuard { LvaeDecTabs* t; ~TabsGuard() { lvae_dec_tabs_free(t); } } tabs{lvae_dec_tabs_new()};
     if (!tabs.t) return -12;
-    struct HotGuard { bool on; HotGuard(bool o) : on(o) { if (on) lvae_coder_pool_hot(1); } ~HotGuard() { if (on) lvae_coder_pool_hot(-1); } } hot{n_images > 1 && n_threads != 1};
     double t_gpu = 0.0, t_coder = 0.0;
     int bad = -1;
     // timeline request: seconds[0] = -(capacity in doubles) on entry -> absolute steady-clock stamps behind the two totals (header)

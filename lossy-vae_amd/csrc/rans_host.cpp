@@ -464,7 +464,6 @@ public:
         for (int i = 0; i < need; ++i) cv_.notify_one();          // (notify_all woke all 64 workers for a 4-stream job)
     }
     int size() const { return (int)th_.size(); }
-    void hot(int delta) { hot_.fetch_add(delta, std::memory_order_relaxed); }
 private:
     Pool() {
         int n = (int)std::thread::hardware_concurrency();
@@ -477,17 +476,15 @@ private:
     // between): a worker that goes to sleep on the condition variable after every call costs a futex wake-up (tens of microseconds) on
     // the critical path of every block.  The first kSpinners workers therefore poll the submit counter for a while (~0.5 ms: longer
     // than a GPU segment between two blocks) before they block; the others sleep at once.
+    // (Keeping them awake for the whole of a decode loop -- no give-up while a loop is in flight -- was measured in round 5: the blocks'
+    //  coder times did not move and the bench lost 1.4 %, profiles/r05_pool_hot_not_taken.txt: not taken.)
     static constexpr int kSpinners = 8;
     void loop(bool spinner) {
         for (;;) {
             std::shared_ptr<Job> j;
             if (spinner) {
-                // (while a decode loop is running -- hot_ > 0 -- the spinners do not give up after ~0.5 ms: the GPU segments between two
-                //  coder calls of the stride-8 / 16 blocks take 0.3-0.6 ms, so every such block used to find its helpers asleep and paid
-                //  their futex wake-up on the decode chain; bounded all the same, a caller that never leaves cannot pin them for good)
                 const unsigned seen = epoch_.load(std::memory_order_acquire);
-                for (int it = 0; epoch_.load(std::memory_order_acquire) == seen && (it < 20000 || (it < 2000000 && hot_.load(std::memory_order_relaxed) > 0)); ++it)
-                    cpu_relax();
+                for (int it = 0; it < 20000 && epoch_.load(std::memory_order_acquire) == seen; ++it) cpu_relax();
             }
             {
                 std::unique_lock<std::mutex> l(m_);
@@ -516,7 +513,6 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::atomic<unsigned> epoch_{0};
-    std::atomic<int> hot_{0};                   // decode loops in flight (lvae_coder_pool_hot)
     std::deque<std::shared_ptr<Job>> q_;
     std::vector<std::thread> th_;
 };
@@ -611,10 +607,6 @@ int lvae_rans_encode_batch_end(LvaeEncJob* e) {
     delete e;
     return rc;
 }
-
-// plan_runtime.cpp brackets a pipeline group's decode loop with (+1, -1): the pool's spinning workers then stay awake between the
-// loop's per-block coder calls (Pool::loop)
-void lvae_coder_pool_hot(int delta) { Pool::get().hot(delta); }
 
 // lvae_rans_decode_batch with caller-owned decode tables (plan_runtime.cpp: one table set for the nine per-block calls of a decode);
 // the tables must have been made for this (qcdf, cdf_len) by lvae_dec_tabs_new and die with lvae_dec_tabs_free

@@ -230,7 +230,10 @@ def mlptrace():
     """In-kernel timeline of csrc/mlp_h2c.hip (experimental build with -DH2C_EXP_TRACE, LVAE_LIB=...): wave 0 of workgroup 0, second tile."""
     from lvae._native import MlpDesc
     from lvae.models.base import pack_f16x2_k32
-    C, HID, M = 192, 384, int(os.environ.get('LVAE_TRACE_M', '196608'))
+    C, HID = (int(v) for v in os.environ.get('LVAE_MLP_SHAPE', '192,384').split(','))
+    M = int(os.environ.get('LVAE_TRACE_M', '196608'))
+    HC = {(192, 384): 128, (128, 192): 64, (384, 768): 128}[(C, HID)]          # the instance's hidden chunk / column parts (csrc/mlp_h2c.hip)
+    NSUB = 3 if C == 384 else 1
     yf = torch.randn(M, C, device='cuda')
     W1, W2 = torch.randn(HID, C, device='cuda') / C ** 0.5, torch.randn(C, HID, device='cuda') / HID ** 0.5
     b1, b2, gamma = torch.randn(HID, device='cuda'), torch.randn(C, device='cuda'), torch.rand(C, device='cuda')
@@ -245,10 +248,13 @@ def mlptrace():
     torch.cuda.synchronize()
     t = out[M * C:].view(torch.int64)[:128].cpu().numpy().astype('int64')
     t0 = t[0]
-    PT, KS1 = 10, 6
-    print('pos kind : wait_dma  barrier  stage(behind barrier -> next stage begins)   [cycles, s_memtime]')
-    for P in range(30):
-        nxt = t[3 * (P + 1)] if P < 29 else t[104]
+    KS1 = C // 32
+    PT = KS1 + (HC // 32) * NSUB
+    NP = (HID // HC) * PT
+    assert 3 * NP <= 96, 'trace slots'
+    print(f'mlp_h2c<{C}, {HID}, {HC}>: pos kind : wait_dma  barrier  stage(behind barrier -> next stage begins)   [cycles, s_memtime]')
+    for P in range(NP):
+        nxt = t[3 * (P + 1)] if P < NP - 1 else t[104]
         kind = ('F%d' % (P % PT)) if P % PT < KS1 else ('G%d' % (P % PT - KS1))
         extra = ''
         if P % PT == KS1 - 1:
