@@ -269,7 +269,8 @@ extern "C" int lvae_rans_enc_step_selftest(uint64_t x, uint32_t start, uint32_t 
 //      BEFORE the state is; if cf falls inside the mode -- a compare the branch predictor learns on compressible data: by definition
 //      the mode is what a stream mostly holds -- the state update is  shift -> multiply -> add  with no table load in the chain
 //      (~5 cycles instead of ~11).  A stream whose symbols are not mostly modes (hit rate below ~80 % over 1024 symbols: each miss is a
-//      mispredicted branch) turns the path off for a while and probes again later; the decoded symbols never depend on that.
+//      mispredicted branch) turns the path off for a while and probes again later -- except on rows whose mode alone holds >= 80 % of the
+//      mass, where the model itself predicts the hit; the decoded symbols never depend on any of that.
 //   2. pure bucket: most of a row's probability mass sits in symbols much wider than a bucket, so ONE pair of loads (freq, start:
 //      two 16-bit tables, no unpacking shift in the chain) yields the update and the symbol id comes off the critical path;
 //   3. only buckets that contain a boundary take the scan.
@@ -279,7 +280,7 @@ extern "C" int lvae_rans_enc_step_selftest(uint64_t x, uint32_t start, uint32_t 
 // and by the nine per-block calls of a decode (lvae_decode_blocks) -- building the ~64 rows costs 25-35 us, which used to sit on the
 // decode chain once per latent block and stream.
 struct RowTab { uint16_t freq[256]; uint16_t start[256]; uint8_t lut[256]; };
-struct RowInfo { uint32_t mfreq, mstart; int32_t msym, max_value; };       // mfreq = 0: the row has no most-probable-symbol path
+struct RowInfo { uint32_t mfreq, mstart; int32_t msym, max_value; uint32_t mpeak; };       // mfreq = 0: the row has no most-probable-symbol path; mpeak = mfreq if the mode alone holds >= 80 % of the row's mass, else 0
 struct LvaeDecTabs {
     RowTab tabs[256];
     RowInfo info[256];
@@ -293,6 +294,9 @@ inline void spin_pause() {
     __builtin_ia32_pause();
 #endif
 }
+// A row whose mode holds at least this share of the mass (0.8 * 2^16) tries the mode path even while the stream-level switch is off: the
+// model itself says the compare will mostly hit there (break-even of the path is a hit rate of ~0.77)
+constexpr uint32_t kMpsPeak = 52429;
 // -> false: the row's cdf length is out of range
 inline bool ensure_row(LvaeDecTabs& D, int row, const int32_t* cdf, int32_t size) {
     uint8_t st = D.state[row].load(std::memory_order_acquire);
@@ -326,6 +330,7 @@ inline bool ensure_row(LvaeDecTabs& D, int row, const int32_t* cdf, int32_t size
         const uint32_t f = (uint32_t)(cdf[s + 1] - cdf[s]);
         if (cdf[s] >= 0 && cdf[s + 1] <= 65536 && cdf[s + 1] > cdf[s] && f > R.mfreq) { R.mfreq = f; R.mstart = (uint32_t)cdf[s]; R.msym = s; }
     }
+    R.mpeak = R.mfreq >= kMpsPeak ? R.mfreq : 0;
     D.state[row].store(2, std::memory_order_release);
     return true;
 }
@@ -369,7 +374,7 @@ int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n
         const RowInfo& R = D.info[row_i];
         const uint32_t cf = (uint32_t)(x & 0xFFFF);
         const uint32_t dm = cf - R.mstart;
-        if (__builtin_expect(use_mps && dm < R.mfreq, 1)) {
+        if (__builtin_expect(dm < (use_mps ? R.mfreq : R.mpeak), 1)) {
             // the row's mode: start / freq came from the scale index, nothing in the chain but shift, multiply, add
             x = (uint64_t)R.mfreq * (x >> kPrecision) + dm;
             if (x < kRansL) {
