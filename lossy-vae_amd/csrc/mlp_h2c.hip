@@ -29,7 +29,7 @@
 #include <utility>
 
 #if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2C_EXP_NOGELU) || defined(H2C_EXP_NOADMA) || defined(H2C_EXP_NOWDMA) || defined(H2C_EXP_NOMFMA) || \
-    defined(H2C_EXP_NOEPI) || defined(H2C_EXP_NODSR) || defined(H2C_EXP_NOBAR) || defined(H2C_EXP_TRACE))
+    defined(H2C_EXP_NOEPI) || defined(H2C_EXP_NODSR) || defined(H2C_EXP_NOBAR) || defined(H2C_EXP_TRACE) || defined(H2C_EXP_NOARES))
 #error "H2C_EXP_* ablations (wrong results by construction: they remove work to time what is left) need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
 #endif
 // H2C_EXP_TRACE: in-kernel timeline (s_memtime) of wave 0 of workgroup 0 on its SECOND tile, written behind the output rows
@@ -63,8 +63,14 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_>
+template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_, bool ARES_ = false>
 struct H2C {
+    // ARES (round 5; the <128, 192, 64> instance, which leaves 56 KB of the CU's LDS unused): the tile's A rows are RESIDENT -- fetched once
+    // per tile into their own region (C / 32 stages of BM rows x 128 B) instead of once per hidden chunk into the ring, an F stage's ring
+    // slot then holds the chunk's W1 rows only.  The next tile's A rows are requested during the current tile's last chunk, as soon as
+    // their stage has had its last reader (H2C::nextra): no position of a tile waits for a cold fetch from HBM any more (position 2 did:
+    // 3-5 us per tile, profiles/r05_mlp_h2c_128x192_ablations.txt), and a third of the kernel's DMA bytes is gone.
+    static constexpr bool ARES = ARES_;
     // HC: hidden chunk (128; 64 where 128 does not divide the hidden width).  BM: rows per tile (128; 64 where a 128-row output tile does
     // not fit the registers: C = 384).  NSUB: a G stage holds the W2 rows of C / NSUB output columns (1; 3 for C = 384: 128 rows = 16 KB)
     static constexpr int C = C_, HID = HID_, BM = BM_, HC = HC_, NSUB = NSUB_;
@@ -78,17 +84,38 @@ struct H2C {
     static constexpr int NBS = C / (NSUB * 32 * WNN);    // output column blocks of a wave in ONE G stage
     static constexpr int NB2 = NSUB * NBS;               // output column blocks of a wave
     static constexpr int NBM = NBF > NBS ? NBF : NBS;
-    static constexpr int SLOT = ((BM + HC) > C / NSUB ? (BM + HC) : C / NSUB) * 128, NBUF = NBUF_, RING = NBUF * SLOT;   // a stage: BM A rows + HC W1 rows | C / NSUB W2 rows
+    static constexpr int FROWS = ARES ? HC : BM + HC;    // rows of an F stage's ring slot
+    static constexpr int SLOT = (FROWS > C / NSUB ? FROWS : C / NSUB) * 128, NBUF = NBUF_, RING = NBUF * SLOT;   // a stage: [BM A rows +] HC W1 rows | C / NSUB W2 rows
     static constexpr int HBYTES = KS2 * BM * 128;        // hidden chunk: HC / 32 stages of BM rows x 128 B
-    static constexpr int LDS = RING + HBYTES;
+    static constexpr int ABYTES = ARES ? KS1 * BM * 128 : 0;   // resident A tile
+    static constexpr int AOFF = RING + HBYTES;
+    static constexpr int LDS = RING + HBYTES + ABYTES;
     static constexpr int LA = NBUF - 1;                  // DMA look-ahead in stage positions (3-slot ring: two; 4 slots where LDS has the room and the stages are short)
     static constexpr int NA = BM / 64;                   // DMA instruction rounds that cover the A rows (8 rows each, 8 waves)
+    static constexpr int NW1 = HC / 64;                  // DMA instruction rounds that cover the W1 rows of a chunk
     static constexpr int NI_F = (BM + HC) / 64;          // DMA instructions per wave: F stage (A rows + W1 rows)
     static constexpr int NI_G = C / NSUB / 64;           // ... G stage (C / NSUB rows of W2)
     static_assert(HID % HC == 0 && BM % 64 == 0 && HC % (32 * WNN) == 0 && C % (NSUB * 32 * WNN) == 0 && (C / NSUB) % 64 == 0 && NP % NBUF == 0 && NBM <= 3, "shape");
+    static_assert(HC % 64 == 0, "W1 rows in whole DMA rounds");
+    static_assert(!ARES || (KS1 == 4 && NBUF_ == 3 && NCH >= 2), "resident A rows: the schedule of H2C::nextra is written for four A stages and a look-ahead of two");
     static_assert(LDS <= 160 * 1024, "LDS");
     static constexpr bool is_f(int p) { return (p % PT) < KS1; }
-    static constexpr int ni(int p) { return is_f(p % NP) ? NI_F : NI_G; }
+    // DMA instructions per wave of the group of tile-relative position p (issued during position p - LA).  ARES: an F stage's group is
+    // the chunk's W1 rows only; the NEXT tile's A rows are extra instructions of the LAST chunk's stages (nextra): A stage 0 during the
+    // position behind its last reader (the last chunk's F0), A stage 1 one later -- six to seven microseconds before anyone waits for
+    // them --, A stages 2 / 3 at the very end of the tile's last position, so that the wait in front of the epilogue's stores can leave
+    // exactly them outstanding (loads retire in order): they are first needed at the next tile's position 2
+    static constexpr int ni(int p) {
+        const int q = p % NP;
+        if (!is_f(q)) return NI_G;
+        return ARES ? NW1 : NI_F;
+    }
+    static constexpr int nextra(int p) {
+        if (!ARES || p < 0) return 0;
+        const int q = p % NP;
+        return (q == (NCH - 1) * PT + 1 || q == (NCH - 1) * PT + 2) ? NA : (q == NP - 1 ? 2 * NA : 0);
+    }
+    static constexpr int nextra_between(int p) { int n = 0; for (int x = p - LA; x < p; ++x) n += nextra(x); return n; }   // extras younger than position p's group
     static constexpr int ni_between(int p) { int n = 0; for (int x = p + 1; x < p + LA; ++x) n += ni(x); return n; }   // DMA instructions younger than position p's
 };
 
@@ -102,14 +129,15 @@ __device__ __forceinline__ void h2c_frags_landed(f16x8 (&a)[2], f16x8 (*w)[2]) {
 #endif
 }
 
-template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_> // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
+template <int C_, int HID_, int HC_, int BM_, int NSUB_, int NBUF_, bool ARES_> // (integer parameters: a kernel template over a type of the anonymous namespace gets no host stub symbol)
 __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, int n_tiles) {
     // (device pass only: hipcc's HOST pass cannot instantiate the generic lambdas below -- the kernel template then silently drops out
     //  of overload resolution and no launch stub is emitted; the host needs nothing but the stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang fp contract(off)
-    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_>;
+    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_, ARES_>;
     constexpr int LA = S::LA;
+    constexpr bool ARES = S::ARES;
     constexpr int C = S::C, HID = S::HID, BM = S::BM, KS1 = S::KS1, KS2 = S::KS2, PT = S::PT, NP = S::NP, NB2 = S::NB2, NBF = S::NBF, NBS = S::NBS, NSUB = S::NSUB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,7 +179,10 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         int wv = wave;
         asm volatile("" : "+s"(wv));
         const int g = i * 8 + wv;
-        if constexpr (Q < KS1) {                         // F stage Q of chunk CH: A rows 0 .. BM - 1 | W1 rows CH * HC .. + HC - 1, k32 index Q
+        if constexpr (Q < KS1 && ARES) {                 // F stage Q of chunk CH, resident A rows: the chunk's W1 rows, k32 index Q
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, dvA,
+                                                     (CH * S::HC + 8 * g) * (C * 4) + Q * 128, 0, 0);
+        } else if constexpr (Q < KS1) {                  // F stage Q of chunk CH: A rows 0 .. BM - 1 | W1 rows CH * HC .. + HC - 1, k32 index Q
             if (i < S::NA) {
 #ifdef H2C_EXP_NOADMA
                 arows = 0;
@@ -169,6 +200,25 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         }
     };
 
+    // ARES: round `ia` (8 rows per wave) of stage `stg` of a tile's resident A rows
+    auto dma_arow = [&](int stg, int ia, const char* abase, int arows) __attribute__((always_inline)) {
+        int wv = wave;
+        asm volatile("" : "+s"(wv));
+        const int ga = ia * 8 + wv;
+#ifdef H2C_EXP_NOADMA
+        arows = 0;
+#endif
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, arows * (C * 4), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)((char*)smem + S::AOFF + stg * (BM * 128) + ga * 1024), 16, dvA,
+                                                 8 * ga * (C * 4) + stg * 128, 0, 0);
+    };
+    // extra instruction e of tile-relative position P (H2C::nextra): the NEXT tile's A rows
+    auto dma_extra = [&](auto ptag, int e, const char* abase, int arows) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value % NP;
+        constexpr int STG0 = P == NP - 1 ? 2 : P - ((S::NCH - 1) * PT + 1);       // first A stage this position fetches
+        dma_arow(STG0 + e / S::NA, e % S::NA, abase, arows);
+    };
+
     // fragment addresses: piece (plane p, k16 step t, lane half) = 4p + 2t + lh at ((piece ^ x) << 4) of the lane's row; the hidden
     // chunk uses rot3 of the row permutation: any bijection of (row >> 1) & 7 keeps the fragment reads conflict-free, and this one also
     // separates rows m and m + 2 in the ds_write_b64 pattern of the GELU phase (4 rows x 4 column groups per 16 lanes), which the plain
@@ -180,8 +230,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
         po[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xr) << 4);
         ph[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xh) << 4);
     }
-    const unsigned a_row = lds0 + (32 * wm + li) * 128;                       // + slot: A rows of an F stage
-    const unsigned w1_row = lds0 + BM * 128 + (32 * NBF * wn + li) * 128;     // + slot: W1 rows of an F stage
+    const unsigned a_row = lds0 + (ARES ? S::AOFF : 0) + (32 * wm + li) * 128;   // + slot: A rows of an F stage (ARES: + stage * BM * 128 of the resident tile)
+    const unsigned w1_row = lds0 + (ARES ? 0 : BM * 128) + (32 * NBF * wn + li) * 128;     // + slot: W1 rows of an F stage
     const unsigned w2_row = lds0 + (wn * 32 * NBS + li) * 128;                // + slot: W2 rows of a G stage
     const unsigned h_row = lds0 + S::RING + (32 * wm + li) * 128;             // + g * 16 KB: hidden rows
 
@@ -195,7 +245,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
     {
         const char* ab = tile_abase(tile);
         const int ar = tile_rows(tile);
-        static_for<LA>([&](auto pp) { static_for<S::NI_F>([&](auto i) { dma_pos(pp, decltype(i)::value, ab, ar); }); });
+        if constexpr (ARES) static_for<KS1 * S::NA>([&](auto e) { dma_arow(decltype(e)::value / S::NA, decltype(e)::value % S::NA, ab, ar); });   // (older than the groups below)
+        static_for<LA>([&](auto pp) { static_for<S::ni(decltype(pp)::value)>([&](auto i) { dma_pos(pp, decltype(i)::value, ab, ar); }); });
     }
 
     f32x16 oH[NB2], oX[NB2], pH[NBF], pX[NBF];
@@ -234,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             constexpr int OB = F ? 0 : ((Q - KS1) % NSUB) * NBS;
             constexpr int OBP = (F || Q == KS1) ? 0 : ((Q - KS1 - 1) % NSUB) * NBS;      // ... of the previous G stage (whose second k16 step runs here)
             constexpr int P2 = P + LA;                                       // the position whose DMAs are issued during this stage
-            constexpr int NI2 = S::ni(P2);
+            constexpr int NIG = S::ni(P2), NI2 = NIG + S::nextra(P);             // this stage's DMA instructions: the group of P2, then the extras of P
             const char* ab2 = P2 >= NP ? ab_nxt : ab_cur;
             const int ar2 = P2 >= NP ? ar_nxt : ar_cur;
             if constexpr (Q == 0) {
@@ -250,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             // tile's epilogue stores.
             H2C_T(3 * P);
             if (P >= LA || first) {
-                constexpr int ALLOW = S::ni_between(P) + ((CH == S::NCH - 1 && Q >= KS1 && Q < KS1 + LA) ? 4 * NB2 : 0);
+                constexpr int ALLOW = S::ni_between(P) + S::nextra_between(P) + ((CH == S::NCH - 1 && Q >= KS1 && Q < KS1 + LA) ? 4 * NB2 : 0);
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ALLOW) : "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -264,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
             int issued = 0;
             // (opaque: the per-slot, per-piece addresses are recomputed per stage -- a few v_add in MFMA shadows -- instead of being hoisted
             //  out of the tile loop as ~30 loop-invariant registers, which hipcc then spills)
-            unsigned aq = F ? a_row + SL * S::SLOT : h_row + KK * (BM * 128);
+            unsigned aq = F ? (ARES ? a_row + Q * (BM * 128) : a_row + SL * S::SLOT) : h_row + KK * (BM * 128);
             unsigned wq = (F ? w1_row : w2_row) + SL * S::SLOT;
             asm volatile("" : "+v"(aq), "+v"(wq));
             const unsigned* pa = F ? po : ph;                                 // piece offsets of the A side (hidden chunk: rot3 permutation)
@@ -286,7 +337,8 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                             else oH[O + b] = H2C_MFMA(a[0], w[b][0], oH[O + b]);
                         }
                     }
-                    if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                    if (issued < NIG) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                    else if (issued < NI2) { dma_extra(ptag, issued - NIG, ab_nxt, ar_nxt); ++issued; }
                     LVAE_FENCE();
                 }
             };
@@ -318,10 +370,11 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                 LVAE_FENCE();
                 mfma_step(ca, cw, std::integral_constant<int, OB>{});
             }
-            static_assert(S::NI_F <= 6 && S::NI_G <= 6, "DMA instructions of a stage must fit behind the MFMA groups of two k16 steps");
+            static_assert(S::NI_F <= 6 && S::NI_G <= 6 && (!S::ARES || S::NW1 + 2 * S::NA <= 6), "DMA instructions of a stage must fit behind the MFMA groups of two k16 steps");
 #pragma unroll
             for (int i2 = 0; i2 < 6; ++i2)                                    // (a run's first stage has three groups only)
-                if (issued < NI2) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                if (issued < NIG) { dma_pos(std::integral_constant<int, P2>{}, issued, ab2, ar2); ++issued; }
+                else if (issued < NI2) { dma_extra(ptag, issued - NIG, ab_nxt, ar_nxt); ++issued; }
             if constexpr (Q == KS1 - 1) {
                 // ---- GELU phase: hidden chunk = split(gelu(P + b1)) -> LDS in the stage layout of an A operand (row m of stage
                 // c / 32: 64 B hi | 64 B lo', 16-B pieces permuted).  After the quad transpose a lane holds 4 consecutive columns of a row.
@@ -399,7 +452,9 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
                     oH[b][4 * g + 0] = v0; oH[b][4 * g + 1] = v1; oH[b][4 * g + 2] = v2; oH[b][4 * g + 3] = v3;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (residual rows long here;) next tile's positions 0 and 1 landed
+            // (residual rows long here;) next tile's positions 0 and 1 landed -- ARES: and its A stages 0 / 1; stages 2 / 3, the youngest
+            // loads, may still be on their way
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ARES ? 2 * S::NA : 0) : "memory");
             H2C_T(105);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -426,16 +481,16 @@ __global__ __launch_bounds__(512, 1) void mlp_h2c_kernel(const lvae_mlp_desc d, 
 #endif
 }
 
-template <int C_, int HID_, int HC_, int BM_ = 128, int NSUB_ = 1, int NBUF_ = 3>
+template <int C_, int HID_, int HC_, int BM_ = 128, int NSUB_ = 1, int NBUF_ = 3, bool ARES_ = false>
 int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
-    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_>;
+    using S = H2C<C_, HID_, HC_, BM_, NSUB_, NBUF_, ARES_>;
     static LdsAttr attr;
-    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_>, S::LDS)) return ae;
+    if (const int ae = attr.ensure((const void*)mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_, ARES_>, S::LDS)) return ae;
     const int n_cu = lvae_cu_count();                       // per device (gemm_common.h), like the LDS attribute above
     if ((long)d->M * S::C * 4 > 0x7fffffffL) return -22;    // 32-bit row offsets in the epilogue, one buffer descriptor per tile base
     const int n_tiles = (d->M + S::BM - 1) / S::BM;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;      // one persistent workgroup per CU (it owns the whole LDS)
-    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
+    hipLaunchKernelGGL((mlp_h2c_kernel<C_, HID_, HC_, BM_, NSUB_, NBUF_, ARES_>), dim3(grid), dim3(512), S::LDS, st, *d, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -445,7 +500,11 @@ int launch_h2c(const lvae_mlp_desc* d, hipStream_t st) {
 extern "C" int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream) {
     if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || d->M <= 0) return -22;
     if (d->C == 192 && d->hid == 384) return launch_h2c<192, 384, 128>(d, (hipStream_t)stream);
+#ifdef H2C_EXP_NOARES
     if (d->C == 128 && d->hid == 192) return launch_h2c<128, 192, 64>(d, (hipStream_t)stream);
+#else
+    if (d->C == 128 && d->hid == 192) return launch_h2c<128, 192, 64, 128, 1, 3, true>(d, (hipStream_t)stream);
+#endif
     if (d->C == 384 && d->hid == 768) return launch_h2c<384, 768, 128, 64, 3, 4>(d, (hipStream_t)stream);
     // (C = 256 / hidden = 448, 512 as <256, hid, 64, 128, 2, 4> was instantiated and measured: bit-identical, 30 spilled registers, 134.7 against
     //  124.3 us at M = 49152, 66.2 against 68.9 at 24576: profiles/r04_mlp_h2c_384x768.txt -- not built into the library)
