@@ -402,7 +402,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(cl_wave
             // row t + 2's NG DMA instructions cannot complete before row t + 1's.  Stores retire independently of loads (a store may
             // overtake an older load), so they must NOT be added to the allowance: an earlier form that allowed NG + 2 for a row's
             // two stores read half-landed rows under memory load.
-            // (Reading the row pixel by pixel behind the taps, each into the register of the pixel that just died, was tried: no gain.)
+            // (Reading the row pixel by pixel behind the taps, each into the register of the pixel that just died, was tried: no gain.
+            //  Round 5: warming L2 with one dword per 128-B line of the tile's rows 2 .. NR - 1 at the tile's start -- LDS-DMA touches older than the
+            //  row DMAs, so that those hit L2 -- was measured SLOWER on every shape, 88 -> 95 us at k = 7 / C = 192, 61 -> 82 at C = 384:
+            //  profiles/r05_dw_l2_touch_not_taken.txt.  The first wait of a tile then waits for all of them.)
 #ifdef LVAE_EXP_DW_NODMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
