@@ -197,7 +197,7 @@ int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
  *     out[m][c] = res[m][c] + gamma[c] * ( fc2( gelu_erf( fc1(y)[m] + b1 ) )[c] + b2[c] )
  * One persistent 512-thread workgroup per CU walks 128-row (C = 384: 64-row) tiles; per tile the hidden dimension is walked in chunks
  * that stay in the CU's LDS, both weight matrices are STREAMED by LDS-DMA (they do not fit a CU).  Instances: (C, hid) = (128, 192) -- the
- * decoder's stride-4 blocks (qarv/zoo.py:86-87), (192, 384) -- the encoder's stride-4 blocks (qarv/zoo.py:38-40) and qres34m's,
+ * decoder's stride-4 blocks (qarv/zoo.py:86-87; since round 5 the tile's A rows are resident in LDS: fetched once per tile, one tile ahead), (192, 384) -- the encoder's stride-4 blocks (qarv/zoo.py:38-40) and qres34m's,
  * (384, 768) -- the stride-8 blocks, taken by the host from M = 49152 rows on (lvae.engine.Plan.FUSED_MLP_MIN_ROWS).  -22 for any other
  * (C, hid) and for M * C * 4 >= 2^31 (32-bit row offsets: the host cuts larger maps into row ranges).
  * y: H2K32 planes [M][C] (lvae_dwconv_ln_h2); w1: H2K32 [hid][C]; w2: H2K32 [C][hid] (lvae.models.base.pack_f16x2_k32); res / out: fp32
