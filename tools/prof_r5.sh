@@ -40,5 +40,7 @@ python $R/tools/dec_timeline.py 8 20 2>&1 | grep -v amdgpu > $O/dec_timeline_b8.
 python $R/tools/dec_timeline.py 1 20 2>&1 | grep -v amdgpu > $O/dec_timeline_b1.txt
 python $R/tools/enc_tail.py 8 2>&1 | grep -v amdgpu | tail -1 > $O/enc_tail.txt
 python $R/tools/enc_tail.py 1 2>&1 | grep -v amdgpu | tail -1 >> $O/enc_tail.txt
+LVAE_TIMING=1 python $R/tools/host_overhead.py 8 30 2>&1 | grep -v "amdgpu\|^lvae:" > $O/host_overhead.txt
+LVAE_TIMING=1 python $R/tools/host_overhead.py 1 30 2>&1 | grep -v "amdgpu\|^lvae:" >> $O/host_overhead.txt
 fi
 ls -la $O
