@@ -287,6 +287,118 @@ def host_coder_rate(model, strings, B, H, W):
                     "group's images (9 latent blocks each); bytes re-encoded == bytes decoded"}
 
 
+def _single_stream_ns(tables, sym, idx):
+    """ns per symbol of ONE stream on ONE host thread (the latency of the rANS state chain -- what a latent block's decode waits for),
+    best of 5; also checks that the stream re-encodes to the bytes that were decoded."""
+    from lvae.models.entropy_coding import rans_decode_streams, rans_encode_streams
+    enc = rans_encode_streams(tables, [sym], [idx], 1)
+    out = np.empty_like(sym)
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        rans_decode_streams(tables, enc, [idx], [out], 1)
+        best = min(best, time.perf_counter() - t0)
+    assert np.array_equal(out, sym) and rans_encode_streams(tables, [out], [idx], 1) == enc, 'bytes re-encoded != bytes decoded'
+    return best / max(1, sym.size) * 1e9
+
+
+def _plan_streams(model, B, prec):
+    """(tables, plan, index of the largest latent block) of the decode plan a one-group decode of B images used last."""
+    pl = next(p for k, p in model._plans.items() if k[0] == 'dec' and k[1] == B and k[4] == 0 and k[-1] == prec)
+    li = int(np.argmax([z * hw for z, hw in pl.lat_shapes]))
+    return model._dg().host_tables(), pl, li
+
+
+def coder_workload_rows(model, dev, ims, precision, steps, kind_rows=('typical', 'calibrated')):
+    """One row per coder workload for the batch `ims` under the model's weights: the images as they are ('typical' -- or 'worst_case'
+    when the caller passes the wide-profile model and noise images) and 'calibrated' (latents drawn from the model's own discretised
+    prior: lossy-vae_amd/coder_workloads.py).  Per row: enc / dec ms per step (the bench's step: compress_batch, sync, decompress_batch,
+    sync -- for the calibrated row the encode is that of the sampled reconstruction, the decode that of the calibrated strings), enc+dec
+    Mpixels/s, the streams' mode hit rate / escape rate / bits per symbol, single-stream decode ns per symbol of image 0's largest latent
+    block (bytes re-encoded == bytes decoded is asserted on it)."""
+    import coder_workloads as cw
+    B, _, H, W = ims.shape
+    groups = model.pipeline_groups
+
+    def t_enc(x):
+        for _ in range(2):
+            model.compress_batch(x); torch.cuda.synchronize(dev)
+        t0 = time.time()
+        for _ in range(steps):
+            s = model.compress_batch(x); torch.cuda.synchronize(dev)
+        return (time.time() - t0) / steps * 1e3, s
+
+    def t_dec(strings):
+        for _ in range(2):
+            model.decompress_batch(strings); torch.cuda.synchronize(dev)
+        t0 = time.time()
+        for _ in range(steps):
+            o = model.decompress_batch(strings); torch.cuda.synchronize(dev)
+        return (time.time() - t0) / steps * 1e3, o
+
+    rows = {}
+    for kind in kind_rows:
+        try:
+            if kind == 'calibrated':
+                strings, xhat, st, (syms, idxs) = cw.calibrated_strings(model, B, H // 64, W // 64, seed=1)
+                dec_ms, out = t_dec(strings)
+                assert torch.equal(out, xhat), 'calibrated strings do not decode to the sampled reconstruction'
+                enc_ms, _ = t_enc(xhat)
+                tables = model._dg().host_tables()
+                li = int(np.argmax([s.shape[1] for s in syms]))
+                ns = _single_stream_ns(tables, np.ascontiguousarray(syms[li][0]), np.ascontiguousarray(idxs[li][0]))
+                extra = {'coded_over_table_entropy': round(st['coded_over_entropy'], 5), 'coded_over_ideal': round(st['coded_over_ideal'], 5),
+                         'bits_per_symbol': round(st['bits_per_symbol'], 3), 'bpp': round(st['bpp'], 4),
+                         'note': "latents drawn from the model's own discretised prior block by block (symbol = round(sigma[index] * N(0,1))), coded by the "
+                                 "host coder into the reference's container; decode = decompress_batch of those strings (returns the sampled "
+                                 'reconstruction bit for bit), encode = compress_batch of that reconstruction'}
+            else:
+                enc_ms, strings = t_enc(ims)
+                dec_ms, out = t_dec(strings)
+                model.pipeline_groups = 1
+                model.decompress_batch(strings); torch.cuda.synchronize(dev)
+                model.pipeline_groups = groups
+                tables, pl, li = _plan_streams(model, B, precision)
+                st = cw.stream_stats(tables, pl.sym_np.copy(), pl.idx_np.copy())
+                z, hw = pl.lat_shapes[li]; o = pl.idx_off[li]
+                ns = _single_stream_ns(tables, pl.sym_np[o:o + z * hw].copy(), pl.idx_np[o:o + z * hw].copy())
+                extra = {'bits_per_symbol': round(st['ideal_bits'] / max(1, st['symbols']), 3),
+                         'bpp': round(float(np.mean([len(t) * 8 / (H * W) for t in strings])), 4)}
+            rows[kind] = {'enc_ms_per_step': round(enc_ms, 3), 'dec_ms_per_step': round(dec_ms, 3), 'value': round(B * H * W / (enc_ms + dec_ms) / 1e3, 3),
+                          'unit': 'Mpixels/s', 'steps': steps, 'mode_hit_rate': round(st['mode_hit_rate'], 4), 'escape_rate': round(st['escape_rate'], 5),
+                          'symbols_per_image': int(st['symbols'] // B), 'dec_ns_per_symbol_single_stream': round(ns, 2), **extra}
+        except Exception as e:                               # a side measurement never loses the headline line
+            rows[kind] = {'error': repr(e)}
+        finally:
+            model.pipeline_groups = groups
+    return rows
+
+
+def build_wide_model(device, coder_threads, precision):
+    """The 'wide' seeded-weight profile (posterior x8 / prior x4: symbols span +-20, every table row in use, escapes) -- with uniform-noise
+    images the coder's worst case (SURVEY.md 8(d) 'Synthetic inputs')."""
+    import lvae
+    import seeded_init
+    m = lvae.get_model('qarv_base')
+    sd = m.state_dict()
+    for k in list(sd.keys()):
+        a = seeded_init.seeded_tensor(k, tuple(sd[k].shape), 0, profile='wide')
+        if a is not None:
+            sd[k] = torch.from_numpy(a)
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    m.compress_mode()
+    m.coder_threads = coder_threads
+    m.set_gemm_precision(precision)
+    return m
+
+
+def noise_batch(B, H, W, rank):
+    import seeded_init
+    ims = [seeded_init.synthetic_image_u8(H, W, seed=2000 + rank * 64 + i, kind='noise') for i in range(B)]
+    return torch.from_numpy(np.stack(ims)).permute(0, 3, 1, 2).float().div(255).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -316,6 +428,12 @@ def main():
                     help='extra steps of BASELINE config 3 (qres34m, 8 x 512x768, seeded weights) after the timed region -> qres34m_value (0 = skip)')
     ap.add_argument('--config5-steps', type=int, default=8,
                     help='extra steps of BASELINE config 5 (fp8 mode, 4 x 1216x1216) after the timed region -> config5_value (0 = skip)')
+    ap.add_argument('--size-steps', type=int, default=4,
+                    help='extra steps at the other image sizes BASELINE.json names, headline arithmetic -> other_sizes: 4 x 1216x1216 (Tecnick, padded) and '
+                         '2 x 1408x2048 (CLIC-sized: config 4 shards such images over the GPUs, this is the per-GPU rate) (0 = skip)')
+    ap.add_argument('--coder-steps', type=int, default=8,
+                    help='extra steps per coder-workload row after the timed region -> coder_workloads: typical / calibrated (latents drawn from the '
+                         "model's own prior) / worst_case (wide-profile weights on uniform-noise images) x (batch of 8, single image, config 5) (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -637,6 +755,74 @@ def main():
             config5 = {'error': repr(e)}
         model.set_gemm_precision(args.precision)
 
+    # The other image sizes BASELINE.json names, under the headline's arithmetic: Tecnick (1200x1200 padded to 1216) in a
+    # batch of 4 and a CLIC-2022-sized image pair -- config 4 shards such images over the node's GPUs with no data-path collective, so
+    # its per-GPU rate is this row's.
+    other_sizes = None
+    if world == 1 and args.size_steps > 0 and args.precision in ('f16x2', 'bf16x3') and (B, H, W) == (8, 512, 768):
+        other_sizes = {}
+        model.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+        model.set_gemm_precision(args.precision)
+        for tag, (b_, h_, w_) in (('b4_1216x1216', (4, 1216, 1216)), ('b2_1408x2048', (2, 1408, 2048))):
+            try:
+                xs = synth_batch(b_, h_, w_, rank).to(dev)
+                for _ in range(2):
+                    ss = model.compress_batch(xs); torch.cuda.synchronize(dev); model.decompress_batch(ss); torch.cuda.synchronize(dev)
+                te = td = 0.0
+                for _ in range(args.size_steps):
+                    ta = time.time()
+                    ss = model.compress_batch(xs); torch.cuda.synchronize(dev)
+                    tb = time.time()
+                    oo = model.decompress_batch(ss); torch.cuda.synchronize(dev)
+                    te += tb - ta; td += time.time() - tb
+                te, td = te / args.size_steps * 1e3, td / args.size_steps * 1e3
+                other_sizes[tag] = {'value': round(b_ * h_ * w_ / (te + td) / 1e3, 3), 'unit': 'Mpixels/s', 'enc_ms_per_step': round(te, 3),
+                                    'dec_ms_per_step': round(td, 3), 'steps': args.size_steps, 'precision': args.precision,
+                                    'bpp': round(float(np.mean([len(t) * 8 / (h_ * w_) for t in ss])), 4),
+                                    'psnr_db': round(float(-10 * np.log10(float((oo - xs).square().mean()))), 3),
+                                    'workload': f'qarv_base batch={b_} {h_}x{w_} synthetic, compress_batch+decompress_batch, {args.precision}'}
+                del xs, oo
+            except Exception as e:
+                other_sizes[tag] = {'error': repr(e)}
+
+    # The coder's workload matters for the decode half: the headline's seeded weights on natural-like images give streams
+    # that are 99.4 % mode symbols -- what the host decoder's most-probable-symbol path is fastest on and what no calibrated model writes.
+    # Rows beside it, same step definition: 'calibrated' = latents drawn from the model's own discretised prior (coded size == table entropy),
+    # 'worst_case' = the wide weight profile on uniform-noise images (every table row, escapes); each at the headline's batch, for ONE image
+    # (the reference's protocol) and on config 5.
+    coder_rows = None
+    if world == 1 and args.coder_steps > 0 and args.precision in ('f16x2', 'bf16x3') and (B, H, W) == (8, 512, 768):
+        coder_rows = {}
+        try:
+            model.pipeline_groups = int(os.environ.get('LVAE_GROUPS', '2'))
+            model.set_gemm_precision(args.precision)
+            cs = args.coder_steps
+            coder_rows['b8_512x768'] = coder_workload_rows(model, dev, ims, args.precision, cs)
+            coder_rows['b1_512x768'] = coder_workload_rows(model, dev, ims[:1], args.precision, 2 * cs)
+            if args.config5_steps > 0:
+                model.set_gemm_precision('fp8')
+                ims5 = synth_batch(4, 1216, 1216, rank).to(dev)
+                coder_rows['config5_b4_1216x1216_fp8'] = coder_workload_rows(model, dev, ims5, 'fp8', max(3, cs // 2))
+                model.set_gemm_precision(args.precision)
+                del ims5
+            wide = build_wide_model(dev, model.coder_threads, args.precision)
+            nz = noise_batch(B, H, W, rank).to(dev)
+            coder_rows['b8_512x768']['worst_case'] = coder_workload_rows(wide, dev, nz, args.precision, cs, kind_rows=('typical',))['typical']
+            coder_rows['b1_512x768']['worst_case'] = coder_workload_rows(wide, dev, nz[:1], args.precision, 2 * cs, kind_rows=('typical',))['typical']
+            if args.config5_steps > 0:
+                wide.set_gemm_precision('fp8')
+                nz5 = noise_batch(4, 1216, 1216, rank).to(dev)
+                coder_rows['config5_b4_1216x1216_fp8']['worst_case'] = coder_workload_rows(wide, dev, nz5, 'fp8', max(3, cs // 2), kind_rows=('typical',))['typical']
+                del nz5
+            del wide, nz
+            coder_rows['note'] = ("rows per operating point: 'typical' = the headline's workload (seeded 'typical' weights on natural-like synthetic images: "
+                                  "mode symbols almost throughout), 'calibrated' = latents drawn from the model's own discretised prior (the statistics a "
+                                  "trained model's streams have against its tables), 'worst_case' = seeded 'wide' weights on uniform-noise images (all table "
+                                  'rows, escapes); value = pixels / (enc_ms + dec_ms)')
+        except Exception as e:
+            coder_rows['error'] = repr(e)
+        model.set_gemm_precision(args.precision)
+
     coder = None
     if rank == 0:
         try:
@@ -672,7 +858,7 @@ def main():
             'ref_3080ti_mpx_s': 2.47,
             'roofline': roof, 'roofline_e2e': roofline_e2e, 'fp32_mfma_mode_value': fp32_mode, 'bf16x3_mode_value': bf16x3_mode,
             'b1': b1, 'qres34m_value': None if not qres else qres.get('value'), 'qres34m': qres,
-            'config5_value': None if not config5 else config5.get('value'), 'config5': config5, 'host_coder': coder,
+            'config5_value': None if not config5 else config5.get('value'), 'config5': config5, 'other_sizes': other_sizes, 'coder_workloads': coder_rows, 'host_coder': coder,
         }
         if world == 1 and not args.no_cpu_baseline:
             phys = args.cpu_threads or min(physical_cores(), len(os.sched_getaffinity(0)))

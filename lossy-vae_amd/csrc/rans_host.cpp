@@ -29,6 +29,11 @@ constexpr uint32_t kPrecision = 16;
 constexpr uint32_t kBypassPrecision = 4;
 constexpr int32_t kMaxBypassVal = (1 << kBypassPrecision) - 1;
 constexpr uint64_t kRansL = 1ull << 31;
+// Legal length of a CDF row (cdf_len = own symbols + escape symbol + 1): symbol ids are bytes in the decoder's tables, so a row has at
+// most 256 intervals -- ONE limit for the encoder and the decoder (the encoder used to take 258 and write streams the decoder
+// refused).  The encoder needs two intervals or more (a one-interval row has frequency 2^16, which its 16-bit entry cannot hold); the
+// decoder also reads the one-interval row (every symbol an escape), which the published coder can write.
+constexpr int32_t kMaxCdfLen = 257, kMinCdfLenEnc = 3, kMinCdfLenDec = 2;
 
 struct BackWriter {
     uint32_t* base;
@@ -148,7 +153,7 @@ namespace {
 struct EncEnt { uint64_t rcp; uint32_t bias; uint16_t freq; uint8_t shift; uint8_t ready; };      // 16 bytes
 struct EncRow {
     int32_t offset = 0, max_value = 0;
-    EncEnt e[258];                                       // values 0 .. max_value (the escape symbol is entry max_value)
+    EncEnt e[kMaxCdfLen - 1];                            // values 0 .. max_value (the escape symbol is entry max_value)
 };
 inline void enc_ent_init(EncEnt& s, uint32_t start, uint32_t freq) {
     s.freq = (uint16_t)freq;                             // 1 <= freq <= 65535: a row has at least two symbols of frequency >= 1
@@ -180,8 +185,8 @@ struct EncTabs {
     // -> nullptr: the row's cdf length is out of range
     EncRow* row(int r, const int32_t* cdf_len, const int32_t* offset) {
         if (rows[r]) return rows[r].get();
+        if (cdf_len[r] < kMinCdfLenEnc || cdf_len[r] > kMaxCdfLen) return nullptr;
         const int32_t mv = cdf_len[r] - 2;
-        if (mv < 1 || mv > 256) return nullptr;
         rows[r].reset(new EncRow);
         rows[r]->offset = offset[r];
         rows[r]->max_value = mv;
@@ -308,7 +313,7 @@ inline bool ensure_row(LvaeDecTabs& D, int row, const int32_t* cdf, int32_t size
         spin_pause();
         st = D.state[row].load(std::memory_order_acquire);
     }
-    if (size < 2 || size > 257) { D.state[row].store(3, std::memory_order_release); return false; }
+    if (size < kMinCdfLenDec || size > kMaxCdfLen) { D.state[row].store(3, std::memory_order_release); return false; }
     RowTab& T = D.tabs[row];
     int32_t sidx = 0;
     for (int b = 0; b < 256; ++b) {
