@@ -208,6 +208,21 @@ typedef struct {
     int M, C, hid;
 } lvae_mlp_desc;
 int lvae_mlp_h2f(const lvae_mlp_desc* d, void* stream);
+
+/* The MLP of a ConvNeXt block on the SMALL maps (stride 32 / 64: both GEMMs run split-K there), csrc/mlp_sk.hip (round 6):
+ * out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with fc1's K = C in S1 slices and fc2's K = hid in S2 >= 2 slices, as TWO launches
+ * instead of three or four -- workgroup (32 rows, slice c) computes the hid / S2 hidden columns of fc2's slice c itself (fc1's S1
+ * slices folded in order), keeps them in LDS and writes fc2's partial sums to plane c of `ws` (S2 planes of M x C floats); the
+ * split-K reduce launch then finishes.  Every output bit equals the lvae_gemm_f32 launches it replaces (prec 4, a_h2 / out_h2,
+ * ksplit = S1 for fc1 and S2 for fc2: reference lvae/models/common.py:154-158 computes the same MLP in fp32).  y / w1 / w2 in H2K32
+ * ([M][C], [hid][C], [C][hid]); res and out may alias.  Shapes: lvae_mlp_sk_supported(C, hid, S1, S2) != 0. */
+typedef struct {
+    const void* y; const void* w1; const float* b1; const void* w2; const float* b2; const float* gamma;
+    const float* res; float* out; float* ws;
+    int M, C, hid, S1, S2;
+} lvae_mlp_sk_desc;
+int lvae_mlp_sk(const lvae_mlp_sk_desc* d, void* stream);
+int lvae_mlp_sk_supported(int C, int hid, int S1, int S2);
 int lvae_gemm_num_configs(void);      /* number of selectable tile configurations */
 
 /* Native replay of a recorded launch-plan segment (csrc/plan_runtime.cpp; lvae/engine.py: Plan.run): ONE foreign call instead of one
@@ -218,9 +233,10 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 enum {
     LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_DWCONV_LN_Q8, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
     LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
-    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_ORDER
+    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_MLP_SK, LVAE_OP_ORDER
 };
 typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
+#define LVAE_TRACE_MAGIC 1985229328.0      /* lvae_decode_blocks: seconds[1] of a timeline request */
 int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int* failed_index);
 
 /* One pipeline group's DECODE as a single foreign call (replaces the per-latent-block Python loop around the reference's
@@ -236,9 +252,10 @@ int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_stream, int
  * written under another arithmetic.  A stream that fails to decode (-74) is reported as -75 (EOVERFLOW) when the word is set at that
  * point (garbage indexes, not a corrupt stream).  The caller zeroes the device word again.
  * Returns 0, a launch error (failed_block = block, failed_op = index in its segment; block n_blocks = the tail), -75 (above), or -74
- * (EBADMSG) when a stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional) receive the time spent waiting for the GPU
- * segments and inside the coder.  Timeline (measurement): with seconds[0] = -(capacity of the array in doubles, >= 8) on entry, absolute
- * steady-clock stamps (s) follow the two totals: per block b, seconds[2 + 4 b ..] = segment launch begins / segment + index copy issued /
+ * (EBADMSG) when a stream is corrupt / truncated (failed_block = its block).  seconds[0] / [1] (optional: an array of TWO doubles or more,
+ * output) receive the time spent waiting for the GPU segments and inside the coder.  Timeline (measurement; IN/out): with BOTH
+ * seconds[0] = -(capacity of the array in doubles, 8 ... 4096) and seconds[1] = LVAE_TRACE_MAGIC on entry -- an uninitialised output array
+ * never is -- absolute steady-clock stamps (s) follow the two totals, clamped to that capacity: per block b, seconds[2 + 4 b ..] = segment launch begins / segment + index copy issued /
  * indexes on the host / block decoded and its symbols on their way to the device; seconds[2 + 4 n_blocks] = tail issued. */
 typedef struct {
     const lvae_op* ops; int n_ops;

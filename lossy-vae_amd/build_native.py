@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lvae', '_native')
 OUT = os.path.join(OUT_DIR, 'liblvae_hip.so')
-SOURCES = ['gemm_f32.hip', 'gemm_f32_patch2.hip', 'gemm_f32_conv3.hip', 'gemm_x3v2.hip', 'gemm_h2.hip', 'gemm_h2p.hip', 'gemm_h2n.hip', 'mlp_h2c.hip', 'gemm_lp.hip', 'gemm_q8.hip', 'pointwise.hip', 'dwconv_cl.hip', 'dwconv_cl_bf16.hip', 'dwconv_cl_h2.hip', 'dwconv_cl_q8.hip', 'rans_host.cpp', 'plan_runtime.cpp']
+SOURCES = ['gemm_f32.hip', 'gemm_f32_patch2.hip', 'gemm_f32_conv3.hip', 'gemm_x3v2.hip', 'gemm_h2.hip', 'gemm_h2p.hip', 'gemm_h2n.hip', 'mlp_h2c.hip', 'mlp_sk.hip', 'gemm_lp.hip', 'gemm_q8.hip', 'pointwise.hip', 'dwconv_cl.hip', 'dwconv_cl_bf16.hip', 'dwconv_cl_h2.hip', 'dwconv_cl_q8.hip', 'rans_host.cpp', 'plan_runtime.cpp']
 HEADERS = ['gemm_common.h', 'device_math.h']
 INCLUDED = {'dwconv_cl_bf16.hip': 'dwconv_cl.hip', 'dwconv_cl_h2.hip': 'dwconv_cl.hip', 'dwconv_cl_q8.hip': 'dwconv_cl.hip', 'gemm_f32_patch2.hip': 'gemm_f32.hip', 'gemm_f32_conv3.hip': 'gemm_f32.hip'}   # wrapper -> the source it #includes
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'lvae_hip.h')

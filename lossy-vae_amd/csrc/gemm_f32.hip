@@ -669,6 +669,15 @@ __global__ void splitk_reduce_kernel(const lvae_gemm_desc d, int S) {
 
 extern "C" int lvae_gemm_num_configs(void) { return 12; }
 
+// The second pass of a parallel split-K GEMM as a launch of its own (csrc/mlp_sk.hip writes the S planes itself): out = epilogue(sum over
+// the planes in slice order + bias) -- splitk_reduce_chunk, the function every split-K form ends in.
+int lvae_splitk_reduce_launch(const lvae_gemm_desc* d, int S, hipStream_t st) {
+    if (!d || S < 2 || (d->N & 3) || (d->ldo & 3) || (d->ldres & 3) || !d->ws || !d->out) return -22;
+    const long n = (long)d->M * (d->N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d, S);
+    return (int)hipGetLastError();
+}
+
 int lvae_gemm_x3v2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);      // gemm_x3v2.hip
 int lvae_gemm_h2_try(const lvae_gemm_desc* d, hipStream_t st, int force_tn, int* rc);        // gemm_h2.hip
 int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force_tile, int* rc);     // gemm_h2p.hip

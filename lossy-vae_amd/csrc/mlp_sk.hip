@@ -1,0 +1,280 @@
+// mlp_sk.hip -- the MLP of a ConvNeXt block on the SMALL maps (stride 32 / 64 of the codec: 96 ... 3072 rows per launch, C = 512,
+// hidden = 1024 ... 2048), fc1 -> GELU -> fc2 partial sums as ONE launch + the split-K reduce launch
+// (reference: lvae/models/common.py:131-132,154-158 -- `mlp(x)` of ConvNeXtBlockAdaLN, one nn.Module there).
+//
+// Why.  On these maps a launch has a handful of row tiles and megabytes of weights, so both GEMMs run split-K (lvae/engine.py::
+// auto_ksplit: S1 = 2 ... 4 slices of fc1's K = C, S2 = 8 ... 16 slices of fc2's K = hidden; the slice counts fix the summation order and
+// with it every bit of the bitstream contract).  Rounds 3-5 ran them as two or three launches -- fc1 (serial split-K, gemm_h2p FOLD), fc2
+// (parallel split-K, gemm_h2) + reduce, or fc2 serial -- 35-45 us per block on the dependency chain of BOTH the encoder and the decoder,
+// although a block is 1.6-4.8 GFLOP and 6-8 MB of weights: no launch of the chain takes less than ~5 us and the long-K fc2 tiles cannot
+// fill the chip.  The observation behind this kernel: fc2's K slice c IS a contiguous range of hidden columns [c CH, (c + 1) CH),
+// CH = hidden / S2 -- so the workgroup (row tile, slice c) can compute exactly those hidden columns itself (fc1 restricted to CH output
+// columns: all S1 slices of its K = C, folded in slice order like gemm_h2p's FOLD form), apply bias / GELU / the f16x2 split in
+// registers, keep the 32 x CH hidden tile in LDS, and multiply it with slice c of W2: the partial sums of fc2's slice c for its rows --
+// the value the parallel form writes to plane c of the workspace.  The reduce launch (gemm_f32.hip: splitk_reduce_kernel, unchanged) then
+// adds the planes in slice order and applies bias / gamma / residual.  Per accumulator the MFMA sequence, the fold and every
+// elementwise operation are those of the launches replaced, hence the same bits (tests/test_gpu_f16x2.py::test_mlp_sk_equals_split_k_gemms):
+// which form a plan takes is a question of speed only and may depend on the batch.
+//
+// Shape of a workgroup: 32 rows x one slice; NW = CH / 32 waves, each owning ONE 32-column block of the hidden chunk in fc1 and, in
+// fc2, one 32-column block of every group of CH output columns (NGRP = ceil(C / CH) accumulator pairs).  Everything streams through one
+// LDS ring of 3 slots by LDS-DMA in whole 128-B lines (`buffer_load ... lds`: gemm_h2p.hip's scheme -- lane-linear LDS image, bank
+// conflicts removed by permuting the SOURCE address, one raw s_barrier + counted vmcnt per unit): fc1 unit = one k32 stage of the 32
+// y rows + the CH rows of W1; fc2 unit = one k32 stage of CH rows of W2.  A workgroup moves (32 + CH) C 4 + C CH 4 bytes (0.55-1.1 MB, L2
+// hits for all but the first row tile of a slice: the grid is slice-major per XCD) for 12 CH C 32 MFMA-flop: DMA-bound by design --
+// the point is the number of dependent launches, not the matrix pipe.
+#include "gemm_common.h"
+
+int lvae_splitk_reduce_launch(const lvae_gemm_desc* d, int S, hipStream_t st);        // gemm_f32.hip
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define SK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SK_DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define SK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+// Ring depth: as many slots as the LDS holds beside the hidden tile, up to 7.
+template <int CH> struct SkRing { static constexpr int N = (160 * 1024 - 32 * CH * 4) / ((32 + CH) * 128) < 7 ? (160 * 1024 - 32 * CH * 4) / ((32 + CH) * 128) : 7; };
+
+// Roles.  NW = CH / 32 COMPUTE waves (fragment reads + MFMAs + the two epilogues) and NL = 4 LOADER waves that do nothing but issue the
+// LDS-DMA pieces and wait for them.  First form of this kernel: every wave issued its share of a unit's pieces between its MFMAs, as
+// gemm_h2p does -- 12.8 us per workgroup for 576 KB whatever the ring depth (3 or 7 slots), i.e. ~21 B/clk: an LDS-DMA piece costs the
+// ISSUING wave 100-185 cycles when it sits among ds_reads and MFMAs (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), five pieces per
+// wave and unit = the unit's time.  A wave that only loads issues a piece every 25-60 cycles, and the compute waves' loop shrinks to
+// barrier -> 8 ds_read_b128 -> 6 MFMAs.  One s_barrier per unit joins all waves: the loaders arrive when the unit has landed (counted
+// vmcnt), the compute waves when they are done with the unit before; behind it the loaders refill the slot of the unit before.
+// The loader's unit sequence is FLAT over both phases (fc1 stages, then fc2 units: fully unrolled, every vmcnt allowance an immediate),
+// so fc2's first units are on their way while the compute waves are still in fc1 and its GELU epilogue.
+template <int CH, int NGRP, int NQ1>
+__global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_sk_desc d) {
+#pragma clang fp contract(off)
+    constexpr int NW = CH / 32, NL = 4, KS = CH / 32, NBUF = SkRing<CH>::N;
+    constexpr int USZ = (32 + CH) * 128;                            // bytes of a ring slot (an fc1 unit; an fc2 unit needs CH * 128)
+    constexpr int P1 = (4 + CH / 8) / NL, P2 = CH / 8 / NL;         // DMA pieces (8 rows x 128 B) per loader wave: fc1 unit / fc2 unit
+    constexpr int NU2 = NGRP * KS, NUT = NQ1 + NU2;                 // fc2 units; all units
+    static_assert(NBUF >= 3 && (4 + CH / 8) % NL == 0 && (CH / 8) % NL == 0, "whole pieces per loader wave");
+    static_assert((NBUF - 2) * P1 <= 63, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const ring = (char*)smem;
+    char* const hid_lds = ring + NBUF * USZ;                        // [KS][32 rows][128 B]: the GELU'd hidden tile in H2K32 stage form
+    const int S1 = d.S1 > 1 ? d.S1 : 1, S2 = d.S2;
+    const int t = blockIdx.x, c = t % S2, rt = t / S2;             // consecutive workgroups (one per XCD in turn) take consecutive slices
+    const int m0 = rt * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = NQ1 * 32, hid = d.hid;
+    const int rowb1 = C * 4, rowb2 = hid * 4;                       // bytes of an H2K32 row of y / W1, of W2
+
+    if (wave >= NW) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - NW;
+        const int rows_a = (d.M - m0) < 32 ? (d.M - m0) : 32;
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.y + (long)m0 * rowb1), 0, rows_a * rowb1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.w1 + (long)c * CH * rowb1), 0, CH * rowb1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w2, 0, C * rowb2, 0x00020000);
+        const int r_in = lane >> 3, pp = lane & 7;
+        // lane -> (row within the piece's 8, physical 16-B chunk); logical chunk = physical ^ ((unit row >> 1) & 7), unit row = 8 g + r_in.
+        // g = i * NL + lw has the parity of lw (NL is even)
+        const int swz = (pp ^ ((4 * (lw & 1) + (r_in >> 1)) & 7)) << 4;
+        const int voff1 = r_in * rowb1 + swz, voff2 = r_in * rowb2 + swz;
+        auto issue = [&](int idx, int slot) {                       // idx, slot: compile-time after unrolling
+            if (idx < NQ1) {
+#pragma unroll
+                for (int i = 0; i < P1; ++i) {
+                    const int g = i * NL + lw;
+                    const bool isA = g < 4;                         // uniform: the unit's first 32 rows are y's
+                    const int soff = (isA ? 8 * g : 8 * g - 32) * rowb1 + idx * 128;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsY : rsW1, (__attribute__((address_space(3))) void*)(ring + slot * USZ + g * 1024), 16, voff1, soff, 0, 0);
+                }
+            } else {
+                const int u = idx - NQ1, grp = u / KS, ks = u % KS;
+#pragma unroll
+                for (int i = 0; i < P2; ++i) {                      // rows grp * CH + 8 g ... of W2 (beyond C: out of range = zeros), k32 stage c * KS + ks
+                    const int g = i * NL + lw;
+                    const int soff = (grp * CH + 8 * g) * rowb2 + (c * KS + ks) * 128;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(ring + slot * USZ + g * 1024), 16, voff2, soff, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int idx = 0; idx < NBUF - 1; ++idx) issue(idx, idx);
+#pragma unroll
+        for (int idx = 0; idx < NUT; ++idx) {
+            // unit idx has landed when at most the pieces of the units behind it that are already issued (idx + 1 ... idx + NBUF - 2) are outstanding
+            int allow = 0;
+#pragma unroll
+            for (int j = idx + 1; j <= idx + NBUF - 2 && j < NUT; ++j) allow += j < NQ1 ? P1 : P2;
+            switch (allow) {                                        // (an immediate: `allow` is a constant of the unrolled iteration)
+#define SK_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); break;
+                SK_W(0) SK_W(4) SK_W(5) SK_W(6) SK_W(7) SK_W(8) SK_W(9) SK_W(10) SK_W(12) SK_W(13) SK_W(14) SK_W(15) SK_W(16) SK_W(17) SK_W(18) SK_W(19)
+                SK_W(20) SK_W(21) SK_W(22) SK_W(23) SK_W(24) SK_W(25)
+#undef SK_W
+                default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            }
+            if (idx + NBUF - 1 < NUT) issue(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
+            if (idx == NQ1 - 1) asm volatile("s_barrier" ::: "memory");      // the compute waves' "hidden tile complete" barrier
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int li = lane & 31, lh = lane >> 5, lj = li & 3;
+    const int per1 = NQ1 / S1;
+    // fragment addresses: chunk (plane p, k16 step tt, lane half lh) = 4 p + 2 tt + lh of the lane's row, at ((chunk ^ xr) << 4)
+    const int xr = (li >> 1) & 7;
+    unsigned fo[4];                                                 // [2 p + tt]
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) fo[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xr) << 4);
+    const unsigned ring_a = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)ring;
+    const unsigned a_row = ring_a + li * 128, b1_row = ring_a + (32 + wave * 32 + li) * 128, b2_row = ring_a + (wave * 32 + li) * 128;
+    const unsigned h_row = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)hid_lds + li * 128;
+
+    // fc1: P[32 x 32 of this wave] = y W1c^T, S1 slices folded in order
+    f32x16 accH, accX, tot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accH[r] = 0.f; accX[r] = 0.f; tot[r] = 0.f; }
+    int in_slice = 0, slice = 0, buf = 0;
+    for (int s = 0; s < NQ1; ++s) {
+        asm volatile("s_barrier" ::: "memory");
+        SK_FENCE();
+        f16x8 af[2][2], bf[2][2];                                   // [tt][plane]
+        const unsigned ua = a_row + buf * USZ, ub = b1_row + buf * USZ;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
+            SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+            SK_FENCE();
+            accX = SK_MFMA(af[tt][1], bf[tt][0], accX);
+            accX = SK_MFMA(af[tt][0], bf[tt][1], accX);
+            accH = SK_MFMA(af[tt][0], bf[tt][0], accH);
+            SK_FENCE();
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        if (++in_slice == per1) {                                   // end of a K slice of fc1: the partial sum as the parallel form stores it
+            in_slice = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = __builtin_fmaf(accX[r], 1.0f / 2048.0f, accH[r]);
+                if (S1 > 1) pr = pr + 0.0f;                         // (the slab store's "+ bias" with no bias: -0 -> +0)
+                tot[r] = slice == 0 ? pr : tot[r] + pr;
+                accH[r] = 0.f; accX[r] = 0.f;
+            }
+            ++slice;
+        }
+    }
+    // + bias -> GELU -> f16x2 split -> the hidden tile in LDS (stage ks = this wave's 32 columns; rows 4 lh + 8 g + lj after the quad transpose)
+    {
+        const f32x4 vb = *(const f32x4*)(d.b1 + c * CH + wave * 32 + (li & ~3));
+        const int col32 = li & ~3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = tot[4 * g + 0], v1 = tot[4 * g + 1], v2 = tot[4 * g + 2], v3 = tot[4 * g + 3];
+            quad_transpose(v0, v1, v2, v3, lj);
+            v0 += vb[0]; v1 += vb[1]; v2 += vb[2]; v3 += vb[3];
+            gelu_erf4(v0, v1, v2, v3);
+            unsigned h0, l0, h1, l1;
+            split_pair_h2(v0, v1, h0, l0);
+            split_pair_h2(v2, v3, h1, l1);
+            const int r = 4 * lh + 8 * g + lj;
+            char* q = hid_lds + (wave * 32 + r) * 128 + ((col32 & 4) << 1);
+            const int sw = (r >> 1) & 7;
+            *(u32x2_t*)(q + ((((col32 >> 3)) ^ sw) << 4)) = (u32x2_t){h0, h1};
+            *(u32x2_t*)(q + (((4 + (col32 >> 3)) ^ sw) << 4)) = (u32x2_t){l0, l1};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // hidden tile complete (the loaders join this barrier too)
+    SK_FENCE();
+
+    // fc2: O[32 x C] partial over k = the CH hidden columns of slice c
+    f32x16 oH[NGRP], oX[NGRP];
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oH[g][r] = 0.f; oX[g][r] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < NU2; ++u) {
+        const int grp = u / KS, ks = u % KS, ubuf = (NQ1 + u) % NBUF;
+        asm volatile("s_barrier" ::: "memory");
+        SK_FENCE();
+        f16x8 af[2][2], bf[2][2];
+        const unsigned ua = h_row + ks * 4096, ub = b2_row + ubuf * USZ;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
+            SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+            SK_FENCE();
+            oX[grp] = SK_MFMA(af[tt][1], bf[tt][0], oX[grp]);
+            oX[grp] = SK_MFMA(af[tt][0], bf[tt][1], oX[grp]);
+            oH[grp] = SK_MFMA(af[tt][0], bf[tt][0], oH[grp]);
+            SK_FENCE();
+        }
+    }
+    // plane c of the workspace: fma(X, 2^-11, H) + 0.0f, row-major [M][C] (what gemm_h2_kernel's slice c stores: gemm_finish, SLAB)
+    float* const plane = d.ws + (long)c * d.M * C;
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        const int n0 = g * CH + wave * 32;
+        if (n0 >= C) continue;                                      // uniform: the last group of a C that is no multiple of CH
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v0 = __builtin_fmaf(oX[g][4 * q + 0], 1.0f / 2048.0f, oH[g][4 * q + 0]) + 0.0f;
+            float v1 = __builtin_fmaf(oX[g][4 * q + 1], 1.0f / 2048.0f, oH[g][4 * q + 1]) + 0.0f;
+            float v2 = __builtin_fmaf(oX[g][4 * q + 2], 1.0f / 2048.0f, oH[g][4 * q + 2]) + 0.0f;
+            float v3 = __builtin_fmaf(oX[g][4 * q + 3], 1.0f / 2048.0f, oH[g][4 * q + 3]) + 0.0f;
+            quad_transpose(v0, v1, v2, v3, lj);
+            const int row = m0 + 4 * lh + 8 * q + lj;
+            if (row < d.M) *(f32x4*)(plane + (long)row * C + n0 + (li & ~3)) = (f32x4){v0, v1, v2, v3};
+        }
+    }
+}
+
+template <int CH, int NGRP, int NQ1>
+int launch_sk(const lvae_mlp_sk_desc* d, hipStream_t st) {
+    constexpr int LDS = SkRing<CH>::N * (32 + CH) * 128 + 32 * CH * 4;
+    static LdsAttr attr;
+    if (const int ae = attr.ensure((const void*)mlp_sk_kernel<CH, NGRP, NQ1>, LDS)) return ae;
+    const int row_tiles = (d->M + 31) / 32;
+    hipLaunchKernelGGL((mlp_sk_kernel<CH, NGRP, NQ1>), dim3(row_tiles * d->S2), dim3(2 * CH + 256), LDS, st, *d);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int lvae_mlp_sk(const lvae_mlp_sk_desc* d, void* stream) {
+    if (!d || !d->y || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->gamma || !d->res || !d->out || !d->ws || d->M <= 0) return -22;
+    const int C = d->C, hid = d->hid, S1 = d->S1 > 1 ? d->S1 : 1, S2 = d->S2;
+    if (S2 < 2 || (C & 31) || (hid & 31) || hid % S2 || (C / 32) % S1 || (long)d->M * C * 4 > 0x7fffffffL || (long)C * hid * 4 > 0x7fffffffL) return -22;
+    const int CH = hid / S2, ngrp = (C + CH - 1) / CH;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = -22;
+    if (C != 512) return -22;
+    if (CH == 128 && ngrp == 4) rc = launch_sk<128, 4, 16>(d, st);
+    else if (CH == 192 && ngrp == 3) rc = launch_sk<192, 3, 16>(d, st);
+    else if (CH == 256 && ngrp == 2) rc = launch_sk<256, 2, 16>(d, st);
+    if (rc) return rc;
+    // the second pass of the parallel split-K form, unchanged: out = res + gamma * (sum over the S2 planes in slice order + bias)
+    lvae_gemm_desc g = {};
+    g.M = d->M; g.N = C; g.K = hid;
+    g.bias = d->b2; g.gamma = d->gamma; g.res = d->res; g.ldres = C; g.out = d->out; g.ldo = C;
+    g.epi = LVAE_EPI_GAMMA_RES; g.store = LVAE_ST_ROWMAJOR; g.ws = d->ws; g.ksplit = S2;
+    return lvae_splitk_reduce_launch(&g, S2, st);
+}
+
+// 1 when lvae_mlp_sk takes this shape (the host's rule, lvae/engine.py::mlp_sk_ok, asks before it records the launch)
+extern "C" int lvae_mlp_sk_supported(int C, int hid, int S1, int S2) {
+    if (C != 512 || S2 < 2 || S1 < 1 || (hid & 31) || hid % S2 || (C / 32) % S1) return 0;
+    const int CH = hid / S2, ngrp = (C + CH - 1) / CH;
+    return (CH == 128 && ngrp == 4) || (CH == 192 && ngrp == 3) || (CH == 256 && ngrp == 2);
+}

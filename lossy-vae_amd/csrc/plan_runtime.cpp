@@ -71,6 +71,7 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
                 break;
             case LVAE_OP_LOSSLESS_OUTPUT: rc = lvae_lossless_output_f32((const int32_t*)p[0], (const float*)p[1], (float*)p[2], i[0], (int*)p[3], st); break;
             case LVAE_OP_MLP_H2F: rc = lvae_mlp_h2f((const lvae_mlp_desc*)p[0], st); break;
+            case LVAE_OP_MLP_SK: rc = lvae_mlp_sk((const lvae_mlp_sk_desc*)p[0], st); break;
             case LVAE_OP_ORDER:      // i[0] != 0: the side stream waits for the main stream (fork); else the main stream for the side stream (join)
                 rc = i[0] ? lvae_stream_order(stream, side_stream, p[0]) : lvae_stream_order(side_stream, stream, p[0]);
                 break;
@@ -107,10 +108,10 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // The decode loop of one pipeline group (lvae/models/*/model.py: decompress_batch) without the interpreter: the chain
 // GPU segment -> indexes to the host -> rANS -> symbols to the device is latency-bound (nine dependent round trips per image), and with
 // two groups decoding from two Python threads every step of it also queued for the interpreter lock.
-extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings,
-                                  const size_t* string_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
-                                  const int32_t* offset, const lvae_op* tail_ops, int n_tail, const int* status_dev, int* status_host,
-                                  void* stream, void* side_stream, int n_threads, int* failed_block, int* failed_op, double* seconds) {
+static int decode_blocks_impl(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings,
+                              const size_t* string_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                              const int32_t* offset, const lvae_op* tail_ops, int n_tail, const int* status_dev, int* status_host,
+                              void* stream, void* side_stream, int n_threads, int* failed_block, int* failed_op, double* seconds) {
     if (!blocks || n_blocks < 0 || n_images <= 0 || !strings || !string_len || !qcdf || !cdf_len || !offset) return -22;
     hipStream_t st = (hipStream_t)stream;
     std::vector<const uint8_t*> idx_ptr(n_images);
@@ -121,8 +122,10 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
     if (!tabs.t) return -12;
     double t_gpu = 0.0, t_coder = 0.0;
     int bad = -1;
-    // timeline request: seconds[0] = -(capacity in doubles) on entry -> absolute steady-clock stamps behind the two totals (header)
-    const int trace_cap = (seconds && seconds[0] <= -8.0) ? (int)(-seconds[0]) : 0;
+    // timeline request (header): seconds[0] = -(capacity in doubles, 8 ... 4096) AND seconds[1] = LVAE_TRACE_MAGIC on entry -> absolute
+    // steady-clock stamps behind the two totals.  Both words are needed: `seconds` was output-only before the timeline existed, and a C
+    // caller's uninitialised double[2] must never be taken for a capacity
+    const int trace_cap = (seconds && seconds[0] <= -8.0 && seconds[0] >= -4096.0 && seconds[1] == LVAE_TRACE_MAGIC) ? (int)(-seconds[0]) : 0;
     auto stamp = [&](int slot, double t) { if (slot < trace_cap) seconds[slot] = t; };
     for (int b = 0; b < n_blocks; ++b) {
         const lvae_dec_block& k = blocks[b];
@@ -187,10 +190,10 @@ extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, in
     return 0;
 }
 
-extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap,
-                                  long* out_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
-                                  const int* status_dev, int* status_host, void* stream, void* side_stream, int n_threads,
-                                  int* failed_block, int* failed_op, double* seconds) {
+static int encode_blocks_impl(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap,
+                              long* out_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                              const int* status_dev, int* status_host, void* stream, void* side_stream, int n_threads,
+                              int* failed_block, int* failed_op, double* seconds) {
     if (!blocks || n_blocks <= 0 || n_images <= 0 || !out || !out_cap || !out_len || !qcdf || !cdf_len || !offset) return -22;
     hipStream_t st = (hipStream_t)stream;
     std::vector<hipEvent_t> ev(n_blocks, nullptr);
@@ -262,4 +265,33 @@ extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, in
     cleanup();
     if (seconds) { seconds[0] = t1 - t0; seconds[1] = t_wait; seconds[2] = t_coder; }
     return 0;
+}
+
+// The C ABI never lets a C++ exception out (std::bad_alloc from the vectors / the coder's job objects would otherwise unwind through the
+// foreign caller -- ctypes, cgo ... -- and end in std::terminate): -12 (ENOMEM) instead, after the group's stream has drained so that no
+// launch of the failed call still reads the caller's buffers.
+extern "C" int lvae_decode_blocks(const lvae_dec_block* blocks, int n_blocks, int n_images, const uint8_t* const* strings,
+                                  const size_t* string_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
+                                  const int32_t* offset, const lvae_op* tail_ops, int n_tail, const int* status_dev, int* status_host,
+                                  void* stream, void* side_stream, int n_threads, int* failed_block, int* failed_op, double* seconds) {
+    try {
+        return decode_blocks_impl(blocks, n_blocks, n_images, strings, string_len, qcdf, row_stride, cdf_len, offset, tail_ops, n_tail, status_dev,
+                                  status_host, stream, side_stream, n_threads, failed_block, failed_op, seconds);
+    } catch (...) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        return -12;
+    }
+}
+
+extern "C" int lvae_encode_blocks(const lvae_enc_block* blocks, int n_blocks, int n_images, uint8_t* const* out, const size_t* out_cap,
+                                  long* out_len, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
+                                  const int* status_dev, int* status_host, void* stream, void* side_stream, int n_threads,
+                                  int* failed_block, int* failed_op, double* seconds) {
+    try {
+        return encode_blocks_impl(blocks, n_blocks, n_images, out, out_cap, out_len, qcdf, row_stride, cdf_len, offset, status_dev, status_host,
+                                  stream, side_stream, n_threads, failed_block, failed_op, seconds);
+    } catch (...) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        return -12;
+    }
 }

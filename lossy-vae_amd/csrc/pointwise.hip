@@ -822,5 +822,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 21; }
+extern "C" int lvae_abi_version(void) { return 22; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -187,7 +187,8 @@ struct EncTabs {
         if (rows[r]) return rows[r].get();
         if (cdf_len[r] < kMinCdfLenEnc || cdf_len[r] > kMaxCdfLen) return nullptr;
         const int32_t mv = cdf_len[r] - 2;
-        rows[r].reset(new EncRow);
+        rows[r].reset(new (std::nothrow) EncRow);
+        if (!rows[r]) return nullptr;
         rows[r]->offset = offset[r];
         rows[r]->max_value = mv;
         for (auto& e : rows[r]->e) e.ready = 0;
@@ -436,8 +437,9 @@ int decode_stream(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n
 extern "C" int lvae_rans_decode_with_indexes(const uint8_t* in, size_t in_len, const uint8_t* idx, size_t n,
                                              const int32_t* qcdf, int row_stride, const int32_t* cdf_len,
                                              const int32_t* offset, int32_t* sym_out) {
-    std::unique_ptr<LvaeDecTabs> D(new LvaeDecTabs);
-    return decode_stream(in, in_len, idx, n, qcdf, row_stride, cdf_len, offset, sym_out, *D);
+    std::unique_ptr<LvaeDecTabs> D(new (std::nothrow) LvaeDecTabs);
+    if (!D) return -12;
+    try { return decode_stream(in, in_len, idx, n, qcdf, row_stride, cdf_len, offset, sym_out, *D); } catch (...) { return -12; }
 }
 
 namespace {
@@ -551,10 +553,12 @@ extern "C" int lvae_rans_encode_batch(int n_streams, const int32_t* const* sym, 
                                       const int32_t* offset, uint8_t* const* out, const size_t* out_cap,
                                       long* out_len, int n_threads) {
     if (n_streams < 0) return -22;
-    parallel_for(n_streams, n_threads, [&](int s) {
-        out_len[s] = lvae_rans_encode_with_indexes(sym[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, out[s],
-                                                   out_cap[s]);
-    });
+    try {
+        parallel_for(n_streams, n_threads, [&](int s) {
+            out_len[s] = lvae_rans_encode_with_indexes(sym[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, out[s],
+                                                       out_cap[s]);
+        });
+    } catch (...) { return -12; }       // (allocation of the job object; the C ABI lets no exception out)
     int rc = 0;
     for (int s = 0; s < n_streams; ++s) if (out_len[s] < 0) rc = (int)out_len[s];
     return rc;
@@ -584,6 +588,7 @@ LvaeEncJob* lvae_rans_encode_batch_begin(int n_streams, const int32_t* const* sy
     if (n_streams < 0) return nullptr;
     LvaeEncJob* e = new (std::nothrow) LvaeEncJob;
     if (!e) return nullptr;
+    try {
     e->sym.assign(sym, sym + n_streams); e->idx.assign(idx, idx + n_streams); e->n.assign(n, n + n_streams);
     e->out.assign(out, out + n_streams); e->out_cap.assign(out_cap, out_cap + n_streams);
     e->out_len = out_len; e->qcdf = qcdf; e->cdf_len = cdf_len; e->offset = offset; e->row_stride = row_stride;
@@ -599,6 +604,10 @@ LvaeEncJob* lvae_rans_encode_batch_begin(int n_streams, const int32_t* const* sy
         j->run = [](void* c, int i) { ((LvaeEncJob*)c)->run(i); };
         e->job = j;
         Pool::get().submit(j);
+    }
+    } catch (...) {                     // std::bad_alloc from the vectors / the job / the pool's queue: nothing was handed to the pool
+        delete e;
+        return nullptr;
     }
     return e;
 }
@@ -626,9 +635,13 @@ int lvae_rans_decode_batch_tabs(int n_streams, const uint8_t* const* in, const s
                                 const size_t* n, const int32_t* qcdf, int row_stride, const int32_t* cdf_len, const int32_t* offset,
                                 int32_t* const* sym_out, int* status, int n_threads, LvaeDecTabs* tabs) {
     if (n_streams < 0 || !tabs) return -22;
-    parallel_for(n_streams, n_threads, [&](int s) {
-        status[s] = decode_stream(in[s], in_len[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, sym_out[s], *tabs);
-    });
+    try {
+        parallel_for(n_streams, n_threads, [&](int s) {
+            int rc = -12;
+            try { rc = decode_stream(in[s], in_len[s], idx[s], n[s], qcdf, row_stride, cdf_len, offset, sym_out[s], *tabs); } catch (...) {}
+            status[s] = rc;
+        });
+    } catch (...) { return -12; }
     int rc = 0;
     for (int s = 0; s < n_streams; ++s) if (status[s] < 0) rc = status[s];
     return rc;

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 
@@ -41,6 +41,13 @@ class MlpDesc(C.Structure):
                 ('res', C.c_void_p), ('out', C.c_void_p), ('M', C.c_int), ('C', C.c_int), ('hid', C.c_int)]
 
 
+class MlpSkDesc(C.Structure):
+    """Mirror of `lvae_mlp_sk_desc` (lvae_mlp_sk: the MLP of a small-map block whose two GEMMs run split-K, as fused launch + reduce)."""
+    _fields_ = [('y', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('gamma', C.c_void_p),
+                ('res', C.c_void_p), ('out', C.c_void_p), ('ws', C.c_void_p), ('M', C.c_int), ('C', C.c_int), ('hid', C.c_int),
+                ('S1', C.c_int), ('S2', C.c_int)]
+
+
 class DecBlock(C.Structure):
     """Mirror of `lvae_dec_block`: one latent block of a group's decode (lvae_decode_blocks)."""
     _fields_ = [('ops', C.c_void_p), ('n_ops', C.c_int), ('idx_dev', C.c_void_p), ('idx_host', C.c_void_p), ('sym_host', C.c_void_p),
@@ -57,9 +64,10 @@ class EncBlock(C.Structure):
 OP_KINDS = {name: k + 1 for k, name in enumerate([
     'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_dwconv_ln_q8', 'lvae_stem_f32', 'lvae_stem_bf16',
     'lvae_bias_expand_f32', 'lvae_bias_expand_bf16', 'lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32',
-    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f'])}
+    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f', 'lvae_mlp_sk'])}
 OP_ORDER = len(OP_KINDS) + 1
 
+TRACE_MAGIC = 1985229328.0       # LVAE_TRACE_MAGIC
 A_PLAIN, A_PATCH2, A_CONV3 = 0, 1, 2
 STATUS_RANGE, STATUS_NONFINITE_PRIOR, STATUS_NONFINITE_LATENT, STATUS_NONFINITE_IMAGE = 1, 2, 4, 8      # LVAE_STATUS_* (status word)
 EPI_BIAS, EPI_BIAS_GELU, EPI_GAMMA_RES, EPI_RES = 0, 1, 2, 3
@@ -80,6 +88,8 @@ SIGNATURES = {
     'lvae_gemm_f32': (_i, [C.POINTER(GemmDesc), _vp]),
     'lvae_gemm_num_configs': (_i, []),
     'lvae_mlp_h2f': (_i, [C.POINTER(MlpDesc), _vp]),
+    'lvae_mlp_sk': (_i, [C.POINTER(MlpSkDesc), _vp]),
+    'lvae_mlp_sk_supported': (_i, [_i, _i, _i, _i]),
     'lvae_gelu_f32': (_i, [_vp, _vp, _l, _vp]),
     'lvae_dwconv_ln_f32': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),
     'lvae_dwconv_ln_h2': (_i, [_vp] * 8 + [_i] * 5 + [_vp]),

@@ -424,6 +424,37 @@ class Plan:
             self.add(self.lib.lvae_mlp_h2f, (ctypes.byref(d),), label if M <= max_rows else f'{label}[{r0}:]')
         self.flops += 4 * M * C * hid
 
+    # The MLP of a small-map block (both GEMMs split-K) as fused launch + reduce (csrc/mlp_sk.hip, round 6): same bits as the split-K
+    # launches whichever form runs them, so the rule may look at the batch.  Taken up to this many rows per launch (beyond, the
+    # pre-split serial split-K launches fill the chip and stream each weight once per 128 rows instead of once per 32).
+    MLP_SK_MAX_ROWS = int(os.environ.get('LVAE_MLP_SK_MAX_ROWS', '1024'))
+
+    def mlp_sk_ok(self, C, hid, k, rows_per_image, M, n_affine=1):
+        """f16x2 plans: (S1, S2) when the block's MLP runs as lvae_mlp_sk, else None.  Only where the two-launch alternative is split-K
+        with S2 >= 2 (maps below H2P_MIN_ROWS_PER_IMAGE rows per image); the slice counts are the per-image rule's (auto_ksplit)."""
+        if self.MLP_SK_MAX_ROWS <= 0 or M > self.MLP_SK_MAX_ROWS:
+            return None
+        if not self.mlp_h2p_ok(C, hid, k, n_affine, None) or self.mlp_h2p_ok(C, hid, k, n_affine, rows_per_image):
+            return None
+        S1 = auto_ksplit(rows_per_image, hid, C, _native.ST_ROWMAJOR, hid, 0, 4)
+        S2 = auto_ksplit(rows_per_image, C, hid, _native.ST_ROWMAJOR, C, C, 4)
+        if S2 < 2 or not self.lib.lvae_mlp_sk_supported(C, hid, S1, S2):
+            return None
+        return S1, S2
+
+    def mlp_sk(self, *, y, M, C, hid, S1, S2, w1, b1, w2, b2, gamma, res, out, label='mlp'):
+        """out = res + gamma * (fc2(gelu(fc1(y) + b1)) + b2) with y pre-split (lvae_dwconv_ln_h2), fc1 in S1 and fc2 in S2 K slices."""
+        assert self.prec == 4
+        w1h, w2h = self.w16_k32.get(w1), self.w16_k32.get(w2)
+        assert w1h and w2h, f'{label}: weights do not fit the pre-split operand format'
+        d = _native.MlpSkDesc()
+        d.y, d.w1, d.b1, d.w2, d.b2, d.gamma, d.res, d.out = y, w1h, b1, w2h, b2, gamma, res, out
+        d.ws = self.buf(self.sname('splitk_ws'), S2 * M * C).data_ptr()
+        d.M, d.C, d.hid, d.S1, d.S2 = M, C, hid, S1, S2
+        self.keep.append(d)
+        self.add(self.lib.lvae_mlp_sk, (ctypes.byref(d),), label)
+        self.flops += 4 * M * C * hid
+
     # ---- execution
     # opt-in: measured +-0.5% at B=1 (the path is GPU-latency-bound, not launch-bound) and HIP's global capture mode
     # conflicts with the two pipeline-group threads launching concurrently (hipErrorStreamCaptureInvalidated).

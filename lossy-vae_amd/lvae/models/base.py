@@ -342,7 +342,7 @@ class CodecBase(nn.Module):
         trace = getattr(self, 'dec_trace', None)             # measurement hook (tools/dec_timeline.py): a list collects per-block stamps
         secs = (ctypes.c_double * (64 if trace is not None else 2))()
         if trace is not None:
-            secs[0] = -64.0
+            secs[0], secs[1] = -64.0, _native.TRACE_MAGIC          # timeline request: capacity AND the magic word (include/lvae_hip.h)
         ss = pl.side_stream.cuda_stream if pl.side_stream is not None else None
         st_dev = pl.status_ptr() if self.status_checks else None
         with torch.cuda.device(pl.device):

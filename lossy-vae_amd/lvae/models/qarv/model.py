@@ -253,6 +253,14 @@ class _NetPlan(Plan):
             self.mlp_fused(y=y.data_ptr(), M=M, C=C, hid=hid, w1=pk.p(p + '.fc1_w'), b1=pk.p(p + '.fc1_b'), w2=pk.p(p + '.fc2_w'),
                            b2=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'), res=x, out=out, label=p + '.mlp')
             return
+        sk = self.mlp_sk_ok(C, hid, k, H * W, M)
+        if sk is not None:
+            # stride-32 / 64 maps (both GEMMs split-K): fc1 -> GELU -> fc2's partial sums as one launch, then the reduce launch (csrc/mlp_sk.hip)
+            self.add(lib.lvae_dwconv_ln_h2, (x, pk.p(p + '.dw_w'), pk.p(p + '.dw_b'), None, None, ptr(pk.adaln, off), ptr(pk.adaln, off + C),
+                                             y.data_ptr(), self.B, H, W, C, k), p + '.dwln')
+            self.mlp_sk(y=y.data_ptr(), M=M, C=C, hid=hid, S1=sk[0], S2=sk[1], w1=pk.p(p + '.fc1_w'), b1=pk.p(p + '.fc1_b'), w2=pk.p(p + '.fc2_w'),
+                        b2=pk.p(p + '.fc2_b'), gamma=pk.p(p + '.gamma'), res=x, out=out, label=p + '.mlp')
+            return
         if self.mlp_q8_ok(C, hid, k):
             pre1, pre2, S1, S2 = True, True, None, None
         else:

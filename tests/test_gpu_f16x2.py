@@ -405,6 +405,46 @@ def test_mlp_h2c_equals_two_gemms(M, C, HID):
     assert float((out.double() - ref64).abs().max()) < 1e-4 * float(ref64.abs().max())
 
 
+@pytest.mark.parametrize('C,HID,S1,S2', [(512, 2048, 4, 16), (512, 1024, 4, 8), (512, 1536, 2, 8), (512, 2048, 2, 8), (512, 1024, 1, 8)])
+@pytest.mark.parametrize('M', [96, 100, 384, 1536, 3072 + 5])
+def test_mlp_sk_equals_split_k_gemms(M, C, HID, S1, S2):
+    """The small-map MLP (csrc/mlp_sk.hip: workgroup (32 rows, fc2 slice c) computes its hid / S2 hidden columns itself -- fc1's S1 slices
+    folded in order -- and writes fc2's partial sums to plane c; then the split-K reduce launch) against the two serial split-K launches
+    it replaces (gemm_h2p FOLD: fc1 with ksplit = S1 and the pre-split GELU epilogue, fc2 with ksplit = S2, gamma + residual), which
+    tests above tie to the parallel split-K form: every output bit equal.  Shapes: the model's stride-64 / 32 blocks (hidden 2048 / 16
+    slices, 1024 / 8, 1536 / 8 with its 192-column chunks and a partial third output group), a 1216x1216 image's stride-64 block (2048 /
+    8: 256-column chunks), S1 = 1; M = 96 / 384 / 1536: one and four images, 100 / 3077: ragged last row tile.  In place like the plans."""
+    from lvae import _native
+    from lvae.models.base import pack_f16x2_k32
+    assert _native.lib().lvae_mlp_sk_supported(C, HID, S1, S2) == 1
+    g = torch.Generator().manual_seed(M + HID + S1)
+    yf = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    yf[3] = 0.0
+    W1 = (torch.randn(HID, C, generator=g) / C ** 0.5).cuda()
+    W2 = (torch.randn(C, HID, generator=g) / HID ** 0.5).cuda()
+    b1, b2, gamma = torch.randn(HID, generator=g).cuda(), torch.randn(C, generator=g).cuda(), torch.rand(C, generator=g).cuda()
+    b1[5] = 0.0
+    res = torch.randn(M, C, generator=g).cuda()
+    y, w1h, w2h = pack_f16x2_k32(yf), pack_f16x2_k32(W1), pack_f16x2_k32(W2)
+    hid = torch.empty(M, HID, device='cuda')                           # H2K32 planes, 4 bytes per element
+    ref = torch.full((M, C), float('nan'), device='cuda')
+    ws = torch.full((S2 * M * C,), float('nan'), device='cuda')
+    assert _gemm(y, C, C, W1, w1h, b1, hid, HID, M, 1, a_h2=1, out_h2=1, ksplit=S1, ws=ws) == 0
+    assert _gemm(hid, HID, HID, W2, w2h, b2, ref, C, M, 2, gamma=gamma, res=res, a_h2=1, ksplit=S2, ws=ws) == 0
+    d = _native.MlpSkDesc()
+    out = res.clone()
+    d.y, d.w1, d.b1, d.w2, d.b2, d.gamma = y.data_ptr(), w1h.data_ptr(), b1.data_ptr(), w2h.data_ptr(), b2.data_ptr(), gamma.data_ptr()
+    d.res, d.out, d.ws, d.M, d.C, d.hid, d.S1, d.S2 = out.data_ptr(), out.data_ptr(), ws.data_ptr(), M, C, HID, S1, S2
+    for rep in range(3):
+        out.copy_(res)
+        ws.fill_(float('nan'))
+        assert _native.lib().lvae_mlp_sk(ctypes.byref(d), _st()) == 0
+        torch.cuda.synchronize()
+        assert not torch.isnan(ref).any() and torch.equal(out, ref), f'rep {rep}: {int((out != ref).sum())} of {out.numel()} elements differ'
+    ref64 = res.double() + gamma.double() * (F.gelu(yf.double() @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double())
+    assert float((out.double() - ref64).abs().max()) < 1e-4 * float(ref64.abs().max())
+
+
 @pytest.mark.parametrize('M', [5, 128, 129, 1000, 24576 + 77, 256 * 128 + 1, 98304, 196608])
 def test_mlp_h2f_equals_two_gemms(M):
     """The fused MLP of the C = 128 / hidden = 192 blocks (lvae_mlp_h2f -> csrc/mlp_h2c.hip <128, 192, 64>: fc1 -> GELU -> fc2 in one launch, hidden chunks of 64 in LDS)

@@ -310,3 +310,36 @@ def test_most_probable_symbol_path_on_odd_tables(L):
     rc = L.lvae_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, n, cdf.ctypes.data, stride, ln.ctypes.data, off.ctypes.data, dec.ctypes.data)
     assert rc == 0 and np.array_equal(dec, sym)
     assert np.array_equal(_oracle_dec(s, idx, cdf, ln, off), sym)
+
+
+@pytest.mark.parametrize('cdf_len,ok', [(257, True), (258, False), (3, True), (2, False)])
+def test_row_length_limit_is_the_same_for_encoder_and_decoder(L, cdf_len, ok):
+    """one limit for the legal length of a CDF row on both sides (3 <= cdf_len <= 257 for the encoder; the decoder's symbol
+    ids are bytes).  A 257-entry row (255 own symbols + escape) round-trips and equals the oracle's bytes; a 258-entry row, which the
+    encoder used to take and the decoder to refuse, is refused by both (-4); a 2-entry row (escape only) is not writable here."""
+    n_int = cdf_len - 1                                   # intervals: own symbols + the escape symbol
+    cdf = np.zeros((1, 264), np.int32)
+    edges = np.linspace(0, 65536, n_int + 1).astype(np.int64)
+    edges[-1] = 65536
+    cdf[0, :cdf_len] = edges
+    ln, off = np.array([cdf_len], np.int32), np.array([-5], np.int32)
+    g = np.random.default_rng(cdf_len)
+    n = 5000
+    idx = np.zeros(n, np.uint8)
+    sym = g.integers(-12, n_int + 4, size=n).astype(np.int32)      # own symbols and escapes on both sides
+    out = np.empty(8 * n + 64, dtype=np.uint8)
+    nb = L.lvae_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, n, cdf.ctypes.data, cdf.shape[1], ln.ctypes.data, off.ctypes.data, out.ctypes.data, out.size)
+    if not ok:
+        assert nb == -4
+        junk = np.zeros(64, np.uint8)
+        dec = np.empty(n, np.int32)
+        rc = L.lvae_rans_decode_with_indexes(junk.ctypes.data, junk.size, idx.ctypes.data, n, cdf.ctypes.data, cdf.shape[1], ln.ctypes.data, off.ctypes.data, dec.ctypes.data)
+        assert rc == (-4 if cdf_len > 257 else rc)              # (the decoder also reads the one-interval row the published coder can write)
+        return
+    assert nb >= 8
+    s = out[:nb].tobytes()
+    assert s == cs.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist())
+    dec = np.empty(n, np.int32)
+    buf = np.frombuffer(s, dtype=np.uint8)
+    rc = L.lvae_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, n, cdf.ctypes.data, cdf.shape[1], ln.ctypes.data, off.ctypes.data, dec.ctypes.data)
+    assert rc == 0 and np.array_equal(dec, sym)
