@@ -35,26 +35,32 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define SK_DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 #define SK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
-// Ring depth: as many slots as the LDS holds beside the hidden tile, up to 7.
-template <int CH> struct SkRing { static constexpr int N = (160 * 1024 - 32 * CH * 4) / ((32 + CH) * 128) < 7 ? (160 * 1024 - 32 * CH * 4) / ((32 + CH) * 128) : 7; };
+// Roles.  NW = CH / 32 COMPUTE waves (fragment reads + MFMAs + the two epilogues) and NL LOADER waves that do nothing but issue the
+// LDS-DMA pieces (8 rows x 128 B = 1 KiB per wave instruction) and wait for them.  Why loaders, and why eight of them
+// (profiles/r06_cu_ingest.txt, tools/ubench/cu_ingest.hip): ONE wave moves 5.7 B/clk by LDS-DMA whatever it waits on (13.8 GB/s: ~180
+// cycles per piece), W waves W times that up to the CU's ~54 B/clk -- so a workgroup's streaming rate is its number of ISSUING waves.
+// First form of this kernel: the four compute waves issued the pieces between their MFMAs (gemm_h2p's scheme): 12.8 us per workgroup
+// for 576 KB at any ring depth = 21 B/clk; four dedicated loaders: 11.2 us (the same four issuers); eight loaders: see the profile.
+// A unit = SPU k32 stages; one s_barrier per unit joins all waves: the loaders arrive when the unit has landed (counted vmcnt), the
+// compute waves when they are done with the unit before; behind it the loaders refill that unit's slot.  The loaders' unit sequence is
+// FLAT over both phases (fc1 units, then fc2 units: fully unrolled, every vmcnt allowance an immediate), so fc2's first units are on
+// their way while the compute waves are still in fc1 and its GELU epilogue.
+template <int CH, int SPU> struct SkRing {
+    static constexpr int USZ = SPU * (32 + CH) * 128;
+    static constexpr int FIT = (160 * 1024 - 32 * CH * 4) / USZ;
+    static constexpr int N = FIT < 7 ? FIT : 7;
+};
 
-// Roles.  NW = CH / 32 COMPUTE waves (fragment reads + MFMAs + the two epilogues) and NL = 4 LOADER waves that do nothing but issue the
-// LDS-DMA pieces and wait for them.  First form of this kernel: every wave issued its share of a unit's pieces between its MFMAs, as
-// gemm_h2p does -- 12.8 us per workgroup for 576 KB whatever the ring depth (3 or 7 slots), i.e. ~21 B/clk: an LDS-DMA piece costs the
-// ISSUING wave 100-185 cycles when it sits among ds_reads and MFMAs (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), five pieces per
-// wave and unit = the unit's time.  A wave that only loads issues a piece every 25-60 cycles, and the compute waves' loop shrinks to
-// barrier -> 8 ds_read_b128 -> 6 MFMAs.  One s_barrier per unit joins all waves: the loaders arrive when the unit has landed (counted
-// vmcnt), the compute waves when they are done with the unit before; behind it the loaders refill the slot of the unit before.
-// The loader's unit sequence is FLAT over both phases (fc1 stages, then fc2 units: fully unrolled, every vmcnt allowance an immediate),
-// so fc2's first units are on their way while the compute waves are still in fc1 and its GELU epilogue.
-template <int CH, int NGRP, int NQ1>
-__global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_sk_desc d) {
+template <int CH, int NGRP, int NQ1, int NL, int SPU>
+__global__ __launch_bounds__(64 * (CH / 32 + NL), 1) void mlp_sk_kernel(const lvae_mlp_sk_desc d) {
 #pragma clang fp contract(off)
-    constexpr int NW = CH / 32, NL = 4, KS = CH / 32, NBUF = SkRing<CH>::N;
-    constexpr int USZ = (32 + CH) * 128;                            // bytes of a ring slot (an fc1 unit; an fc2 unit needs CH * 128)
-    constexpr int P1 = (4 + CH / 8) / NL, P2 = CH / 8 / NL;         // DMA pieces (8 rows x 128 B) per loader wave: fc1 unit / fc2 unit
-    constexpr int NU2 = NGRP * KS, NUT = NQ1 + NU2;                 // fc2 units; all units
-    static_assert(NBUF >= 3 && (4 + CH / 8) % NL == 0 && (CH / 8) % NL == 0, "whole pieces per loader wave");
+    constexpr int NW = CH / 32, KS = CH / 32, NBUF = SkRing<CH, SPU>::N;
+    constexpr int ST1 = (32 + CH) * 128, ST2 = CH * 128;            // bytes of one k32 stage inside a slot: fc1 (32 y rows + CH W1 rows) / fc2 (CH W2 rows)
+    constexpr int USZ = SkRing<CH, SPU>::USZ;                       // bytes of a ring slot
+    constexpr int NG1 = 4 + CH / 8, NG2 = CH / 8;                   // DMA pieces of one stage
+    constexpr int P1 = SPU * NG1 / NL, P2 = SPU * NG2 / NL;         // ... per loader wave and unit
+    constexpr int NU1 = NQ1 / SPU, NU2 = NGRP * KS / SPU, NUT = NU1 + NU2;
+    static_assert(NBUF >= 2 && (SPU * NG1) % NL == 0 && (SPU * NG2) % NL == 0 && NQ1 % SPU == 0 && KS % SPU == 0, "whole pieces per loader wave, whole units");
     static_assert((NBUF - 2) * P1 <= 63, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const ring = (char*)smem;
@@ -75,26 +81,26 @@ __global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_
         const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.w1 + (long)c * CH * rowb1), 0, CH * rowb1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w2, 0, C * rowb2, 0x00020000);
         const int r_in = lane >> 3, pp = lane & 7;
-        // lane -> (row within the piece's 8, physical 16-B chunk); logical chunk = physical ^ ((unit row >> 1) & 7), unit row = 8 g + r_in.
-        // g = i * NL + lw has the parity of lw (NL is even)
-        const int swz = (pp ^ ((4 * (lw & 1) + (r_in >> 1)) & 7)) << 4;
-        const int voff1 = r_in * rowb1 + swz, voff2 = r_in * rowb2 + swz;
+        // lane -> (row within the piece's 8, physical 16-B chunk); logical chunk = physical ^ ((stage row >> 1) & 7), stage row = 8 g + r_in
+        const int sw0 = (pp ^ ((r_in >> 1) & 7)) << 4, sw1 = (pp ^ ((4 + (r_in >> 1)) & 7)) << 4;      // piece index g even / odd
         auto issue = [&](int idx, int slot) {                       // idx, slot: compile-time after unrolling
-            if (idx < NQ1) {
+            if (idx < NU1) {
 #pragma unroll
                 for (int i = 0; i < P1; ++i) {
-                    const int g = i * NL + lw;
-                    const bool isA = g < 4;                         // uniform: the unit's first 32 rows are y's
-                    const int soff = (isA ? 8 * g : 8 * g - 32) * rowb1 + idx * 128;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsY : rsW1, (__attribute__((address_space(3))) void*)(ring + slot * USZ + g * 1024), 16, voff1, soff, 0, 0);
+                    const int q = i * NL + lw, st = q / NG1, g = q - st * NG1;      // uniform
+                    const bool isA = g < 4;                         // the stage's first 32 rows are y's
+                    const int soff = (isA ? 8 * g : 8 * g - 32) * rowb1 + (idx * SPU + st) * 128;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsY : rsW1, (__attribute__((address_space(3))) void*)(ring + slot * USZ + st * ST1 + g * 1024), 16,
+                                                             r_in * rowb1 + ((g & 1) ? sw1 : sw0), soff, 0, 0);
                 }
             } else {
-                const int u = idx - NQ1, grp = u / KS, ks = u % KS;
+                const int u = idx - NU1, grp = u / (KS / SPU), ks0 = (u % (KS / SPU)) * SPU;
 #pragma unroll
                 for (int i = 0; i < P2; ++i) {                      // rows grp * CH + 8 g ... of W2 (beyond C: out of range = zeros), k32 stage c * KS + ks
-                    const int g = i * NL + lw;
-                    const int soff = (grp * CH + 8 * g) * rowb2 + (c * KS + ks) * 128;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(ring + slot * USZ + g * 1024), 16, voff2, soff, 0, 0);
+                    const int q = i * NL + lw, st = q / NG2, g = q - st * NG2;
+                    const int soff = (grp * CH + 8 * g) * rowb2 + (c * KS + ks0 + st) * 128;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(ring + slot * USZ + st * ST2 + g * 1024), 16,
+                                                             r_in * rowb2 + ((g & 1) ? sw1 : sw0), soff, 0, 0);
                 }
             }
         };
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_
             // unit idx has landed when at most the pieces of the units behind it that are already issued (idx + 1 ... idx + NBUF - 2) are outstanding
             int allow = 0;
 #pragma unroll
-            for (int j = idx + 1; j <= idx + NBUF - 2 && j < NUT; ++j) allow += j < NQ1 ? P1 : P2;
+            for (int j = idx + 1; j <= idx + NBUF - 2 && j < NUT; ++j) allow += j < NU1 ? P1 : P2;
             switch (allow) {                                        // (an immediate: `allow` is a constant of the unrolled iteration)
 #define SK_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); break;
                 SK_W(0) SK_W(4) SK_W(5) SK_W(6) SK_W(7) SK_W(8) SK_W(9) SK_W(10) SK_W(12) SK_W(13) SK_W(14) SK_W(15) SK_W(16) SK_W(17) SK_W(18) SK_W(19)
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_
                 default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
             }
             if (idx + NBUF - 1 < NUT) issue(idx + NBUF - 1, (idx + NBUF - 1) % NBUF);
-            if (idx == NQ1 - 1) asm volatile("s_barrier" ::: "memory");      // the compute waves' "hidden tile complete" barrier
+            if (idx == NU1 - 1) asm volatile("s_barrier" ::: "memory");      // the compute waves' "hidden tile complete" barrier
         }
         return;
     }
@@ -136,38 +142,41 @@ __global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accH[r] = 0.f; accX[r] = 0.f; tot[r] = 0.f; }
     int in_slice = 0, slice = 0, buf = 0;
-    for (int s = 0; s < NQ1; ++s) {
+    for (int un = 0; un < NU1; ++un) {
         asm volatile("s_barrier" ::: "memory");
         SK_FENCE();
-        f16x8 af[2][2], bf[2][2];                                   // [tt][plane]
-        const unsigned ua = a_row + buf * USZ, ub = b1_row + buf * USZ;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
-            SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
-        }
+        for (int st = 0; st < SPU; ++st) {
+            f16x8 af[2][2], bf[2][2];                               // [tt][plane]
+            const unsigned ua = a_row + buf * USZ + st * ST1, ub = b1_row + buf * USZ + st * ST1;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-            SK_FENCE();
-            accX = SK_MFMA(af[tt][1], bf[tt][0], accX);
-            accX = SK_MFMA(af[tt][0], bf[tt][1], accX);
-            accH = SK_MFMA(af[tt][0], bf[tt][0], accH);
-            SK_FENCE();
+            for (int tt = 0; tt < 2; ++tt) {
+                SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
+                SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+                SK_FENCE();
+                accX = SK_MFMA(af[tt][1], bf[tt][0], accX);
+                accX = SK_MFMA(af[tt][0], bf[tt][1], accX);
+                accH = SK_MFMA(af[tt][0], bf[tt][0], accH);
+                SK_FENCE();
+            }
+            if (++in_slice == per1) {                               // end of a K slice of fc1: the partial sum as the parallel form stores it
+                in_slice = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = __builtin_fmaf(accX[r], 1.0f / 2048.0f, accH[r]);
+                    if (S1 > 1) pr = pr + 0.0f;                     // (the slab store's "+ bias" with no bias: -0 -> +0)
+                    tot[r] = slice == 0 ? pr : tot[r] + pr;
+                    accH[r] = 0.f; accX[r] = 0.f;
+                }
+                ++slice;
+            }
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
-        if (++in_slice == per1) {                                   // end of a K slice of fc1: the partial sum as the parallel form stores it
-            in_slice = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_fmaf(accX[r], 1.0f / 2048.0f, accH[r]);
-                if (S1 > 1) pr = pr + 0.0f;                         // (the slab store's "+ bias" with no bias: -0 -> +0)
-                tot[r] = slice == 0 ? pr : tot[r] + pr;
-                accH[r] = 0.f; accX[r] = 0.f;
-            }
-            ++slice;
-        }
     }
     // + bias -> GELU -> f16x2 split -> the hidden tile in LDS (stage ks = this wave's 32 columns; rows 4 lh + 8 g + lj after the quad transpose)
     {
@@ -192,61 +201,65 @@ __global__ __launch_bounds__(2 * CH + 256, 1) void mlp_sk_kernel(const lvae_mlp_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // hidden tile complete (the loaders join this barrier too)
     SK_FENCE();
 
-    // fc2: O[32 x C] partial over k = the CH hidden columns of slice c
-    f32x16 oH[NGRP], oX[NGRP];
-#pragma unroll
-    for (int g = 0; g < NGRP; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oH[g][r] = 0.f; oX[g][r] = 0.f; }
+    // fc2: O[32 x C] partial over k = the CH hidden columns of slice c, one group of CH output columns after the other (a group's
+    // accumulators live only while its units run: its partial sums leave for plane c of the workspace -- fma(X, 2^-11, H) + 0.0f,
+    // row-major [M][C], what gemm_h2_kernel's slice c stores (gemm_finish, SLAB) -- as soon as its last unit is done)
+    float* const plane = d.ws + (long)c * d.M * C;
+    f32x16 oH, oX;
 #pragma unroll
     for (int u = 0; u < NU2; ++u) {
-        const int grp = u / KS, ks = u % KS, ubuf = (NQ1 + u) % NBUF;
+        const int grp = u / (KS / SPU), ks0 = (u % (KS / SPU)) * SPU, ubuf = (NU1 + u) % NBUF;
+        if (ks0 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oH[r] = 0.f; oX[r] = 0.f; }
+        }
         asm volatile("s_barrier" ::: "memory");
         SK_FENCE();
-        f16x8 af[2][2], bf[2][2];
-        const unsigned ua = h_row + ks * 4096, ub = b2_row + ubuf * USZ;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
-            SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
+        for (int st = 0; st < SPU; ++st) {
+            f16x8 af[2][2], bf[2][2];
+            const unsigned ua = h_row + (ks0 + st) * 4096, ub = b2_row + ubuf * USZ + st * ST2;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
+                SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
+                SK_FENCE();
+                oX = SK_MFMA(af[tt][1], bf[tt][0], oX);
+                oX = SK_MFMA(af[tt][0], bf[tt][1], oX);
+                oH = SK_MFMA(af[tt][0], bf[tt][0], oH);
+                SK_FENCE();
+            }
         }
+        if (ks0 + SPU == KS) {                                      // the group's last unit
+            const int n0 = grp * CH + wave * 32;
+            if (n0 < C) {                                           // uniform: the last group of a C that is no multiple of CH
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-            SK_FENCE();
-            oX[grp] = SK_MFMA(af[tt][1], bf[tt][0], oX[grp]);
-            oX[grp] = SK_MFMA(af[tt][0], bf[tt][1], oX[grp]);
-            oH[grp] = SK_MFMA(af[tt][0], bf[tt][0], oH[grp]);
-            SK_FENCE();
-        }
-    }
-    // plane c of the workspace: fma(X, 2^-11, H) + 0.0f, row-major [M][C] (what gemm_h2_kernel's slice c stores: gemm_finish, SLAB)
-    float* const plane = d.ws + (long)c * d.M * C;
-#pragma unroll
-    for (int g = 0; g < NGRP; ++g) {
-        const int n0 = g * CH + wave * 32;
-        if (n0 >= C) continue;                                      // uniform: the last group of a C that is no multiple of CH
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v0 = __builtin_fmaf(oX[g][4 * q + 0], 1.0f / 2048.0f, oH[g][4 * q + 0]) + 0.0f;
-            float v1 = __builtin_fmaf(oX[g][4 * q + 1], 1.0f / 2048.0f, oH[g][4 * q + 1]) + 0.0f;
-            float v2 = __builtin_fmaf(oX[g][4 * q + 2], 1.0f / 2048.0f, oH[g][4 * q + 2]) + 0.0f;
-            float v3 = __builtin_fmaf(oX[g][4 * q + 3], 1.0f / 2048.0f, oH[g][4 * q + 3]) + 0.0f;
-            quad_transpose(v0, v1, v2, v3, lj);
-            const int row = m0 + 4 * lh + 8 * q + lj;
-            if (row < d.M) *(f32x4*)(plane + (long)row * C + n0 + (li & ~3)) = (f32x4){v0, v1, v2, v3};
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = __builtin_fmaf(oX[4 * q + 0], 1.0f / 2048.0f, oH[4 * q + 0]) + 0.0f;
+                    float v1 = __builtin_fmaf(oX[4 * q + 1], 1.0f / 2048.0f, oH[4 * q + 1]) + 0.0f;
+                    float v2 = __builtin_fmaf(oX[4 * q + 2], 1.0f / 2048.0f, oH[4 * q + 2]) + 0.0f;
+                    float v3 = __builtin_fmaf(oX[4 * q + 3], 1.0f / 2048.0f, oH[4 * q + 3]) + 0.0f;
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    const int row = m0 + 4 * lh + 8 * q + lj;
+                    if (row < d.M) *(f32x4*)(plane + (long)row * C + n0 + (li & ~3)) = (f32x4){v0, v1, v2, v3};
+                }
+            }
         }
     }
 }
 
-template <int CH, int NGRP, int NQ1>
+template <int CH, int NGRP, int NQ1, int NL, int SPU>
 int launch_sk(const lvae_mlp_sk_desc* d, hipStream_t st) {
-    constexpr int LDS = SkRing<CH>::N * (32 + CH) * 128 + 32 * CH * 4;
+    constexpr int LDS = SkRing<CH, SPU>::N * SkRing<CH, SPU>::USZ + 32 * CH * 4;
     static LdsAttr attr;
-    if (const int ae = attr.ensure((const void*)mlp_sk_kernel<CH, NGRP, NQ1>, LDS)) return ae;
+    if (const int ae = attr.ensure((const void*)mlp_sk_kernel<CH, NGRP, NQ1, NL, SPU>, LDS)) return ae;
     const int row_tiles = (d->M + 31) / 32;
-    hipLaunchKernelGGL((mlp_sk_kernel<CH, NGRP, NQ1>), dim3(row_tiles * d->S2), dim3(2 * CH + 256), LDS, st, *d);
+    hipLaunchKernelGGL((mlp_sk_kernel<CH, NGRP, NQ1, NL, SPU>), dim3(row_tiles * d->S2), dim3(64 * (CH / 32 + NL)), LDS, st, *d);
     return (int)hipGetLastError();
 }
 
@@ -260,9 +273,9 @@ extern "C" int lvae_mlp_sk(const lvae_mlp_sk_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc = -22;
     if (C != 512) return -22;
-    if (CH == 128 && ngrp == 4) rc = launch_sk<128, 4, 16>(d, st);
-    else if (CH == 192 && ngrp == 3) rc = launch_sk<192, 3, 16>(d, st);
-    else if (CH == 256 && ngrp == 2) rc = launch_sk<256, 2, 16>(d, st);
+    if (CH == 128 && ngrp == 4) rc = launch_sk<128, 4, 16, 8, 2>(d, st);
+    else if (CH == 192 && ngrp == 3) rc = launch_sk<192, 3, 16, 8, 2>(d, st);
+    else if (CH == 256 && ngrp == 2) rc = launch_sk<256, 2, 16, 4, 1>(d, st);
     if (rc) return rc;
     // the second pass of the parallel split-K form, unchanged: out = res + gamma * (sum over the S2 planes in slice order + bias)
     lvae_gemm_desc g = {};
