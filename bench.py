@@ -109,11 +109,31 @@ def launch_work(fn, a):
     if fn is nat.lib().lvae_mlp_h2f:
         m = ctypes.cast(a[0], ctypes.POINTER(nat.MlpDesc)).contents
         return 4.0 * m.M * m.C * m.hid, 12.0 * m.M * m.C + 8.0 * m.C * m.hid
+    if fn is nat.lib().lvae_mlp_sk:             # fused small-map MLP + its reduce launch: the same two GEMMs (the split-K planes are an artefact)
+        m = ctypes.cast(a[0], ctypes.POINTER(nat.MlpSkDesc)).contents
+        return 4.0 * m.M * m.C * m.hid, 12.0 * m.M * m.C + 8.0 * m.C * m.hid
     d = ctypes.cast(a[0], ctypes.POINTER(nat.GemmDesc)).contents
     ea = 2 if d.a_bf16 else 4
     eo = 2 if d.out_bf16 else 4
     ew = {0: 4, 1: 2, 2: 6, 3: 1, 4: 4}[d.prec]
     return 2.0 * d.M * d.N * d.K, float(ea * d.M * d.K + ew * d.N * d.K + eo * d.M * d.N * (2 if d.epi in (2, 3) else 1))
+
+
+def launch_class(fn, a):
+    """Which kernel of the family a recorded launch runs (for the per-kernel rows of `roofline.by_kernel`)."""
+    import ctypes
+    from lvae import _native as nat
+    if fn is nat.lib().lvae_mlp_h2f:
+        m = ctypes.cast(a[0], ctypes.POINTER(nat.MlpDesc)).contents
+        return f'mlp_h2c<{m.C}, {m.hid}> (fused fc1 -> GELU -> fc2)'
+    if fn is nat.lib().lvae_mlp_sk:
+        return 'mlp_sk + splitk_reduce (fused small-map MLP, split-K contract)'
+    d = ctypes.cast(a[0], ctypes.POINTER(nat.GemmDesc)).contents
+    if d.prec != 4:
+        return f'prec {d.prec} GEMM'
+    if d.a_h2:
+        return 'gemm_h2p FOLD (pre-split operands, serial split-K)' if d.ksplit > 1 else 'gemm_h2p (pre-split operands)'
+    return 'gemm_h2 (fp32 A split in the main loop)' + (' + split-K reduce' if d.ksplit > 1 else '')
 
 
 def executed_ops(key, pl):
@@ -148,26 +168,34 @@ def roofline_pass(model, dev, plans, n_steps, step_fn, pred):
     assert len(model._plans) == n_plans, 'the roofline pass must run the plans of the timed region, not build others'
     ms, n = timer.summary()
     flops = bytes_ = 0.0
-    for _e0, _e1, _label, fn, a in timer.pairs:
+    by = {}
+    for e0, e1, _label, fn, a in timer.pairs:
         f, b = launch_work(fn, a)
         flops += f
         bytes_ += b
+        c = by.setdefault(launch_class(fn, a), [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += e0.elapsed_time(e1); c[2] += f; c[3] += b
+    roofline_pass.by_kernel = {k: {'launches_per_step': v[0] // max(1, n_steps), 'avg_launch_us': round(v[1] * 1e3 / v[0], 2),
+                                   'gflop_per_launch': round(v[2] / v[0] / 1e9, 3), 'alg_mbytes_per_launch': round(v[3] / v[0] / 1e6, 2),
+                                   'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0}
+                               for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
     return ms, n, flops, bytes_, expected
 
 
 def attach_traffic(roof, precision, B, H, W):
     """HBM bytes per launch of the family: NOT measured in this run (hardware counters cannot be read from inside the process);
     copied from the committed rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE passes of the same command."""
-    files = {('f16x2', 8, 512, 768): ['r05_pmc_gemm_traffic.json', 'r04_pmc_gemm_traffic.json'], ('bf16x3', 8, 512, 768): ['r02_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic_v8.json'],
-             ('fp8', 4, 1216, 1216): ['r05_pmc_gemm_traffic_fp8_1216.json', 'r03_pmc_gemm_traffic_fp8_1216.json'], ('fp8', 8, 512, 768): ['r02_pmc_gemm_traffic_fp8.json']}
+    files = {('f16x2', 8, 512, 768): ['r06_pmc_gemm_traffic.json'], ('bf16x3', 8, 512, 768): ['r02_pmc_gemm_traffic.json'],
+             ('fp8', 4, 1216, 1216): ['r06_pmc_gemm_traffic_fp8_1216.json'], ('fp8', 8, 512, 768): ['r02_pmc_gemm_traffic_fp8.json']}
     for f in files.get((precision, B, H, W), []):
         tp = os.path.join(REPO, 'profiles', f)
         if os.path.exists(tp):
             tj = json.load(open(tp))
-            roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 1e6)
+            roof['traffic'] = round(tj['hbm_mb_per_launch_corrected'] * 2 ** 20)      # (the counters are KiB: the file's "MB" are MiB)
             roof['traffic_source'] = (f'NOT measured in this run: bytes per launch from the committed rocprofv3 --pmc passes of this '
                                       f"command (profiles/{f}: FETCH_SIZE x2 + WRITE_SIZE over {tj['launches']} launches "
-                                      'of this kernel family); producer outputs still resident in the 256 MiB Infinity Cache are not '
+                                      'of this kernel family; WRITE_SIZE calibrated in round 6 on known byte counts in the store patterns of this library: ratio 1.000, '
+                                      'profiles/r06_write_size_calibration.txt); producer outputs still resident in the 256 MiB Infinity Cache are not '
                                       'counted by the memory-side counters')
             return
 
@@ -496,7 +524,7 @@ def main():
     def dominant(fn, a, label):
         """The dominant kernel = every launch of gemm_kernel<*, PLAIN> (the dense channel-mixing GEMMs: MLP fc1/fc2, i.e. 87%
         of the path's FLOPs, plus post_merge / prior / z_proj / upsample 1x1 convs) -- one rocprofv3 kernel-name family."""
-        if fn is _nat.lib().lvae_mlp_h2f:           # fc1 -> GELU -> fc2 of a block as ONE launch (csrc/mlp_h2f.hip, mlp_h2c.hip): same family, same MFMA stream
+        if fn in (_nat.lib().lvae_mlp_h2f, _nat.lib().lvae_mlp_sk):       # fc1 -> GELU -> fc2 of a block as ONE launch (csrc/mlp_h2c.hip; mlp_sk.hip + its reduce): same family, same MFMA stream
             return True
         if fn is not _nat.lib().lvae_gemm_f32:
             return False
@@ -534,7 +562,7 @@ def main():
     # whole-step algorithmic GEMM FLOPs: every GEMM / fused-MLP launch a step issues from the encode + decode plans of the timed configuration
     timed_plans = [(k, pl) for k, pl in model._plans.items() if k[-1] == args.precision]
     step_gflop = sum(launch_work(fn, a)[0] for k, pl in timed_plans for fn, a, _l, _s in executed_ops(k, pl)
-                     if callable(fn) and fn in (_nat.lib().lvae_gemm_f32, _nat.lib().lvae_mlp_h2f)) / 1e9
+                     if callable(fn) and fn in (_nat.lib().lvae_gemm_f32, _nat.lib().lvae_mlp_h2f, _nat.lib().lvae_mlp_sk)) / 1e9
     ms_step = dt / args.steps * 1e3
     e2e_tf = step_gflop / ms_step                          # GFLOP / ms = TFLOP/s
     roofline_e2e = {
@@ -555,7 +583,7 @@ def main():
         ms, n_launch, flops, alg_bytes, per_step_expected = roofline_pass(model, dev, timed_plans, args.roofline_steps, step, dominant)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        common = {'traffic': None, 'traffic_source': None, 'launches': n_launch, 'launches_per_step': n_launch // max(1, args.roofline_steps),
+        common = {'traffic': None, 'traffic_source': None, 'by_kernel': getattr(roofline_pass, 'by_kernel', None), 'launches': n_launch, 'launches_per_step': n_launch // max(1, args.roofline_steps),
                   'timed_plans_launches_per_step': per_step_expected, 'avg_launch_us': round(ms * 1e3 / max(1, n_launch), 2),
                   'gflop_per_launch': round(flops / max(1, n_launch) / 1e9, 3),
                   'alg_mbytes_per_launch': round(alg_bytes / max(1, n_launch) / 1e6, 2),

@@ -36,7 +36,7 @@ def main(path):
             continue
         simd_cycles = 1024.0 * a['GRBM_GUI_ACTIVE'] / 8.0
         rows.append((a['dur'], name, a))
-        if re.search(r'gemm_h2p_kernel<|gemm_h2_kernel<\d, (true|false), 0>|mlp_h2c_kernel<|mlp_h2f_kernel', name):
+        if re.search(r'gemm_h2p_kernel<|gemm_h2_kernel<\d, (true|false), 0>|mlp_h2c_kernel<|mlp_sk_kernel<|mlp_h2f_kernel', name):
             for k in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'dur', 'n', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_INSTS_MFMA'):
                 fam[k] += a.get(k, 0.0)
     rows.sort(key=lambda r: -r[0])

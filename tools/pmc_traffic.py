@@ -2,7 +2,7 @@
 """HBM traffic per kernel from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, each its own run with --kernel-trace only).
     pmc_traffic.py fetch.db write.db [out.json]
 Units: FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the bytes
-of a wide coalesced streaming read -> 'x2' column; WRITE_SIZE is uncalibrated (reported as is)."""
+of a wide coalesced streaming read -> 'x2' column; WRITE_SIZE is reported as is (round 6: ratio 1.000 against known byte counts in this library's store patterns, profiles/r06_write_size_calibration.txt).  'MB' in the output are MiB (the counters are KiB)."""
 import json
 import re
 import sqlite3
@@ -47,7 +47,7 @@ def main(fetch_db, write_db, out_json=None):
     for name, n, fm, wm in rows[:40]:
         print(f'{short(name):78s} {n:8d} {fm:16.2f} {2 * fm:10.2f} {wm:16.2f}')
     fam = [r for r in rows if (re.search(r'gemm(_x3|_bf16)?_kernel', r[0]) and r[0].rstrip().endswith(', 0>(lvae_gemm_desc, int, int)'))
-           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<|mlp_h2c_kernel<|mlp_h2f_kernel', r[0])]
+           or re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<|mlp_h2c_kernel<|mlp_sk_kernel<|mlp_h2f_kernel', r[0])]
     n = sum(r[1] for r in fam)
     if n:
         fm = sum(r[1] * r[2] for r in fam) / n
@@ -58,7 +58,7 @@ def main(fetch_db, write_db, out_json=None):
             json.dump({'family': 'PLAIN GEMM launches (gemm_h2p/h2/q8/x3k16/x3w8/x3/lp/gemm kernels, AMODE 0)', 'launches': n,
                        'fetch_mb_per_launch_raw': round(fm, 3), 'fetch_mb_per_launch_x2': round(2 * fm, 3),
                        'write_mb_per_launch': round(wm, 3), 'hbm_mb_per_launch_corrected': round(2 * fm + wm, 3),
-                       'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE uncalibrated, taken as is'},
+                       'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is (calibrated: ratio 1.000, profiles/r06_write_size_calibration.txt); units MiB'},
                       open(out_json, 'w'), indent=1)
 
 

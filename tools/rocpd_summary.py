@@ -40,12 +40,12 @@ def main(path, top=40):
     fam = [0, 0]
     for name, a in agg.items():
         if (re.search(r'gemm(_x3|_bf16)?_kernel', name) and name.rstrip().endswith(', 0>(lvae_gemm_desc, int, int)')) or \
-                re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<|mlp_h2c_kernel<', name):
+                re.search(r'gemm_x3k16_kernel<\d, (true|false), 0>|gemm_x3w8_kernel|gemm_lp_kernel<\d, 0, |gemm_h2_kernel<\d, (true|false), 0>|gemm_h2p_kernel<|gemm_q8_kernel<|mlp_h2c_kernel<|mlp_sk_kernel<', name):
             fam[0] += a[0]; fam[1] += a[1]
     tot = sum(a[1] for a in agg.values())
     print(f'# {path}: {len(rows)} dispatches, total kernel time {tot / 1e6:.3f} ms')
     if fam[0]:
-        print(f'# family gemm[_x3|_bf16]_kernel<Cfg<*>, 0> + gemm_x3k16/x3w8/lp/h2/h2p/q8_kernel (PLAIN, all tile configs) + mlp_h2c_kernel (fused fc1 -> GELU -> fc2): {fam[0]} calls, avg {fam[1] / fam[0] / 1e3:.2f} us, '
+        print(f'# family gemm[_x3|_bf16]_kernel<Cfg<*>, 0> + gemm_x3k16/x3w8/lp/h2/h2p/q8_kernel (PLAIN, all tile configs) + mlp_h2c_kernel / mlp_sk_kernel (fused fc1 -> GELU -> fc2): {fam[0]} calls, avg {fam[1] / fam[0] / 1e3:.2f} us, '
               f'total {fam[1] / 1e6:.3f} ms  <- compare with bench.py roofline.avg_launch_us')
     print(f'{"calls":>7} {"total_ms":>10} {"avg_us":>10} {"min_us":>9} {"max_us":>9} {"pct":>6}  kernel')
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
