@@ -360,7 +360,7 @@ class _EncPlan(_NetPlan):
                                              m.out_channels, model.im_shift, model.im_scale, self.status_ptr()), p + '.stem')
                 self.flops += 2 * B * h * w * m.out_channels * 48
             elif m.kind == 'down':
-                if self.side_stream is not None and (h, w) == (H // 16, W // 16) and not hoisted:
+                if self.side_stream is not None and (h, w) == (H // 16, W // 16) and not hoisted and (not small_side or getattr(model, 'hoist_small', True)):
                     self._hoist_posterior0(model, feats, hoisted, H, W)
                 h, w = h // 2, w // 2
                 nx = self.new(B * h * w * m.out_channels, self.adt)

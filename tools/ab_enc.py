@@ -18,10 +18,12 @@ ims = bench.synth_batch(B, 512, 768, 0).to(dev)
 models = []
 for sp in specs:
     g, side = (int(v) for v in sp.split(',')[:2])
-    fused384 = int(sp.split(',')[2]) if len(sp.split(',')) > 2 else None      # third field: row threshold of the (384, 768) fused MLP while this variant's plans are built
+    fused384 = int(sp.split(',')[2]) if len(sp.split(',')) > 2 and sp.split(',')[2] != '' else None      # third field: row threshold of the (384, 768) fused MLP while this variant's plans are built
     m, _ = bench.build_model(dev)
     m.coder_threads = max(8, len(os.sched_getaffinity(0)))
     m.enc_groups, m.side_streams = g, bool(side)
+    if len(sp.split(',')) > 3:                              # fourth field: 0 = small plans (<= 2 x 512x768 pixels) do not hoist posterior0
+        m.hoist_small = bool(int(sp.split(',')[3]))
     from lvae import engine
     saved_rows = dict(engine.Plan.FUSED_MLP_MIN_ROWS)
     if fused384 is not None:

@@ -90,5 +90,23 @@ int main() {
             }
         }
     }
+    // in-flight depth sweep: is a wave's LDS-DMA rate its issue rate or (pieces in flight) / latency?
+    printf("\n%-5s %4s %7s %6s %9s | %10s %10s\n", "kind", "CUs", "regionK", "waves", "in flight", "GB/s/CU", "B/clk/CU");
+    CK(hipFuncSetAttribute((const void*)k_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_dma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_dma<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (long regionK : {128L, 8192L}) {
+        const long region = regionK << 10;
+        const int passes = regionK == 128 ? 32 : 1;
+        const double bytes = (double)region * passes;
+        for (int G : {48, 256}) {
+            for (int W : {1, 2, 4}) {
+#define SWEEP(NF) if (W * NF <= 150) { const float t = timeit([&] { hipLaunchKernelGGL(k_dma<NF>, dim3(G), dim3(64 * W), W * NF * 1024, 0, buf, region, passes, sink); }, 5); \
+                    printf("%-5s %4d %7ld %6d %9d | %10.1f %10.1f\n", "dma", G, regionK, W, NF, bytes / t / 1e6, bytes / t / 1e6 / ghz); }
+                SWEEP(4) SWEEP(8) SWEEP(16) SWEEP(32) SWEEP(60)
+#undef SWEEP
+            }
+        }
+    }
     return 0;
 }
