@@ -184,6 +184,34 @@ def test_fused_mlp_rule_never_trades_split_k_bits_for_a_batch_threshold():
     assert pl.flops == 4 * M * 192 * 384
 
 
+def test_small_map_fused_mlp_rule_keeps_the_split_k_contract():
+    """engine.Plan.mlp_sk_ok (round 6, csrc/mlp_sk.hip): the fused small-map MLP is taken only where the two-launch alternative is
+    split-K (maps below 1536 rows per image), with the PER-IMAGE slice counts of auto_ksplit -- the summation order, hence the bits, do
+    not depend on the batch -- for shapes the library supports, up to MLP_SK_MAX_ROWS rows per launch (a speed rule: same bits either
+    way); never on other arithmetics, never on the large maps (S = 1 there)."""
+    from lvae import _native
+    from lvae.engine import Plan, auto_ksplit
+
+    def plan(B, prec=4):
+        pl = Plan.__new__(Plan)
+        pl.prec, pl.w16_k32, pl.B = prec, {1: 11, 2: 22}, B
+        pl.ops, pl.keep, pl.flops, pl.on_side, pl.lib, pl.bufs = [], [], 0, False, _native.lib(), {}
+        return pl
+    # qarv_base at 512x768: stride 64 (96 rows per image) and stride 32 (384 rows)
+    assert plan(1).mlp_sk_ok(512, 2048, 1, 96, 96) == (4, 16) == plan(4).mlp_sk_ok(512, 2048, 1, 96, 384) == plan(8).mlp_sk_ok(512, 2048, 1, 96, 768)
+    assert plan(1).mlp_sk_ok(512, 1536, 3, 384, 384) == (2, 8)
+    assert plan(1).mlp_sk_ok(512, 1024, 3, 384, 384) == (4, 8) == (auto_ksplit(384, 1024, 512, 0, 1024, 0, 4), auto_ksplit(384, 512, 1024, 0, 512, 512, 4))
+    assert plan(4).mlp_sk_ok(512, 1536, 3, 384, 4 * 384) is None                      # 1536 rows per launch: the serial split-K launches are faster there
+    assert plan(1).mlp_sk_ok(384, 768, 5, 1536, 1536) is None                         # stride-16 map: no split-K, nothing to fuse this way
+    assert plan(1).mlp_sk_ok(256, 448, 7, 96, 96) is None                             # shape the kernel has no instance for
+    assert plan(1, prec=2).mlp_sk_ok(512, 2048, 1, 96, 96) is None                    # other arithmetics: untouched
+    # whichever form runs, the slice counts are mlp_pipeline's
+    for rows, C, hid, k in ((96, 512, 2048, 1), (96, 512, 1024, 1), (384, 512, 1536, 3), (384, 512, 1024, 3)):
+        S1 = auto_ksplit(rows, hid, C, 0, hid, 0, 4); S2 = auto_ksplit(rows, C, hid, 0, C, C, 4)
+        assert plan(1).mlp_sk_ok(C, hid, k, rows, rows) == (S1, S2)
+        assert _native.lib().lvae_mlp_sk_supported(C, hid, S1, S2) == 1
+
+
 def test_numa_pinning_groups_ranks_by_host(monkeypatch):
     """lvae/utils/numa.pin_ranks_collectively on a faked 2-node x 4-GPU job: ranks are grouped by HOSTNAME (identical cpulists on two
     machines must not be pooled), split their node's cores in global-rank order, and refuse a topology that covers < 90 % of the CPUs."""
