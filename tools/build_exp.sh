@@ -9,7 +9,7 @@ N=$R/lossy-vae_amd/lvae/_native
 mkdir -p $R/_bin/$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DLVAE_EXPERIMENTAL_BUILD "$@" -c $R/lossy-vae_amd/csrc/$src -o $R/_bin/$name/$src.o
 objs=""
-for o in gemm_f32.hip gemm_f32_patch2.hip gemm_f32_conv3.hip gemm_x3v2.hip gemm_h2.hip gemm_h2p.hip gemm_h2n.hip mlp_h2c.hip gemm_lp.hip gemm_q8.hip pointwise.hip dwconv_cl.hip dwconv_cl_bf16.hip dwconv_cl_h2.hip dwconv_cl_q8.hip rans_host.cpp plan_runtime.cpp; do
+for o in gemm_f32.hip gemm_f32_patch2.hip gemm_f32_conv3.hip gemm_x3v2.hip gemm_h2.hip gemm_h2p.hip gemm_h2n.hip mlp_h2c.hip mlp_sk.hip gemm_lp.hip gemm_q8.hip pointwise.hip dwconv_cl.hip dwconv_cl_bf16.hip dwconv_cl_h2.hip dwconv_cl_q8.hip rans_host.cpp plan_runtime.cpp; do
   if [ "$o" = "$src" ]; then objs="$objs $R/_bin/$name/$src.o"; else objs="$objs $N/$o.o"; fi
 done
 # EXTRA_SRC="a.hip b.hip": study-only translation units (tools/studies/: e.g. gemm_h2pp.hip, which gemm_h2p.hip calls when built with
