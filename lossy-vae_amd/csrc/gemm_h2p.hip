@@ -23,6 +23,7 @@
 // H: a_hi*w_hi), and the producers' split is the consumer's (exact), so every output bit equals gemm_h2_kernel's on the fp32 operand.
 #include "gemm_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -51,13 +52,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // of the parallel form (gemm_h2_kernel with gridDim.y = S + the reduce kernel / last arriver) in the same order, hence the same bits,
 // without workspace traffic or a second launch.  The host takes it when the BATCH gives enough tiles to fill the chip; the slice count
 // itself stays a function of the per-image shape (lvae/engine.py::auto_ksplit), so batched and single-image calls agree bit for bit.
-template <int WM, int TN, int NBUF, bool FOLD = false>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2))) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
+// NLOAD > 0 (round 6): NLOAD extra LOADER waves issue every LDS-DMA piece and the 2 WM compute waves none.  For the few-tile, long-K
+// launches (serial split-K on the stride-32 / 64 maps: <= one workgroup per CU, 48-64 stages) the stage time WAS the compute waves' DMA
+// issue: an LDS-DMA piece costs its wave ~180 cycles (profiles/r06_cu_ingest.txt), six pieces per wave and stage = 1080 cycles against
+// 384 cycles of MFMAs, with no second workgroup on the CU to hide them.  Eight loaders issue three pieces each; the compute waves' stage
+// is barrier -> fragment reads -> MFMAs.  One s_barrier per stage joins all waves: the loaders arrive when the stage has landed (counted
+// vmcnt), the compute waves when they are done with the stage before, and behind it the loaders refill that stage's slot.  Same MFMA
+// sequence per accumulator, same fold, same epilogue: same bits (tests/test_gpu_f16x2.py::test_gemm_h2p_serial_split_k_*).
+template <int WM, int TN, int NBUF, bool FOLD = false, int NLOAD = 0>
+__global__ __launch_bounds__(128 * WM + 64 * NLOAD, (NLOAD ? 1 : (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2)))) void gemm_h2p_kernel(const lvae_gemm_desc d, int tiles_n, int n_tiles, int stagger) {
     using C = Cfg<WM, 2, 2, TN, 1, 32>;
     constexpr int BM = 64 * WM, BN = 64 * TN, ROWS = BM + BN, STAGE = ROWS * 128;
     constexpr int NWAVE = 2 * WM, NG = ROWS / 8, NI = NG / NWAVE;       // DMA instructions per stage, per wave and stage
     static_assert(NG % NWAVE == 0 && NWAVE % 2 == 0, "whole DMA instructions per wave; g has the parity of the wave");
-    static_assert(NBUF * STAGE <= 160 * 1024 / (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2)), "LDS");
+    static_assert(NBUF * STAGE <= 160 * 1024 / (NLOAD ? 1 : (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2))), "LDS");
+    static_assert(NLOAD == 0 || (NLOAD % 2 == 0 && NG % NLOAD == 0 && (NBUF - 2) * (NG / (NLOAD ? NLOAD : 1)) <= 63), "whole pieces per loader wave; the piece index has the loader's parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int t;
     {
@@ -89,6 +98,35 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.A0 + (long)m0 * rowb), 0, rows_a * rowb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)d.Wt16 + (long)n0 * rowb), 0, rows_w * rowb, 0x00020000);
+    if constexpr (NLOAD > 0) {
+        if (wave >= NWAVE) {
+            // ---- loader waves: piece g = i * NLOAD + lw of every stage (rows 8 g .. 8 g + 7: A rows first), NBUF - 1 stages ahead
+            const int lw = wave - NWAVE;
+            constexpr int PL = NG / NLOAD;
+            const int lr = lane >> 3, lp = lane & 7;
+            const int lvoff = lr * rowb + ((lp ^ ((4 * (lw & 1) + (lr >> 1)) & 7)) << 4);
+            auto issue = [&](int stage, int buf) {
+#pragma unroll
+                for (int i = 0; i < PL; ++i) {
+                    const int g = i * NLOAD + lw;
+                    const bool isA = g < BM / 8;                    // uniform
+                    const int soff = (isA ? 8 * g : 8 * g - BM) * rowb + stage * 128;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsW, (__attribute__((address_space(3))) void*)((char*)smem + buf * STAGE + g * 1024),
+                                                             16, lvoff, soff, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int s = 0; s < NBUF - 1; ++s) issue(s < nq ? s : nq - 1, s);
+            int nb = NBUF - 1;                                      // slot of stage s + NBUF - 1
+            for (int s = 0; s < nq; ++s) {
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * PL) : "memory");
+                issue(s + NBUF - 1 < nq ? s + NBUF - 1 : nq - 1, nb);
+                nb = nb == NBUF - 1 ? 0 : nb + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            return;
+        }
+    }
     // lane -> (row within the instruction's 8, physical piece); logical piece = physical ^ ((stage row >> 1) & 7), stage row = 8g + r_in,
     // g = i * NWAVE + w has the parity of w (NWAVE is even): ((8g + r_in) >> 1) & 7 = (4 (w & 1) + (r_in >> 1)) & 7
     const int r_in = lane >> 3, pp = lane & 7;
@@ -148,17 +186,20 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
 
     // prologue: stages 0 .. NBUF-2 in flight (a stage index beyond the last re-reads the last stage into a free buffer: every iteration
     // then issues exactly NI instructions, which keeps the vmcnt arithmetic uniform)
+    if constexpr (NLOAD == 0) {
 #pragma unroll
-    for (int s = 0; s < NBUF - 1; ++s)
+        for (int s = 0; s < NBUF - 1; ++s)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) dma(i, s < nq ? s : nq - 1, s);
+            for (int i = 0; i < NI; ++i) dma(i, s < nq ? s : nq - 1, s);
+    }
 
     f16x8 af[2][2][2], bf[2][TN][2];                                // [t][a | b][plane]
     auto stage_body = [&](auto buf_tag, int s) {
         constexpr int BUF = decltype(buf_tag)::value, NXT = (BUF + NBUF - 1) % NBUF;
         // my DMA instructions of stage s have landed once at most (NBUF - 2) later stages' are outstanding; after the barrier everyone's
         // have, and everyone is done reading the buffer of stage s - 1 (= the one stage s + NBUF - 1 goes to)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NI) : "memory");
+        if constexpr (NLOAD > 0) asm volatile("s_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NI) : "memory");
         LVAE_FENCE();
         unsigned aa[4], ba[4];
 #pragma unroll
@@ -208,7 +249,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
                         accH[1][b] = H2P_MFMA(af[tt][1][0], bf[tt][b][0], accH[1][b]);
                     }
                     // one DMA instruction of stage s + NBUF - 1 behind each MFMA pair until all NI are out
-                    if (issued < NI) { dma(issued, sn, NXT); ++issued; }
+                    if constexpr (NLOAD == 0) { if (issued < NI) { dma(issued, sn, NXT); ++issued; } }
                     LVAE_FENCE();
                 }
             }
@@ -285,11 +326,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 
 #endif
 }
 
-template <int WM, int TN, int NBUF, bool FOLD = false>
+template <int WM, int TN, int NBUF, bool FOLD = false, int NLOAD = 0>
 int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * TN, LDS = NBUF * (BM + BN) * 128;
     static LdsAttr attr;
-    if (const int ae = attr.ensure((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, LDS)) return ae;
+    if (const int ae = attr.ensure((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD, NLOAD>, LDS)) return ae;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
     static int lds_pad = 0, stagger = 0;
 #ifdef LVAE_EXPERIMENTAL_BUILD           // knobs of the round-3 studies (tools/build_exp.sh copies only; docs/MEASUREMENT_HISTORY.md 5c): extra dynamic LDS (forces
@@ -299,9 +340,9 @@ int launch_h2p(const lvae_gemm_desc* d, hipStream_t st) {
         e = getenv("LVAE_H2P_STAGGER"); stagger = e ? atoi(e) : 0;
         env_read = true;
     }
-    if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
+    if (lds_pad > 0) (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<WM, TN, NBUF, FOLD, NLOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + lds_pad);
 #endif
-    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF, FOLD>), dim3(n_tiles), dim3(128 * WM), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
+    hipLaunchKernelGGL((gemm_h2p_kernel<WM, TN, NBUF, FOLD, NLOAD>), dim3(n_tiles), dim3(128 * WM + 64 * NLOAD), LDS + lds_pad, st, *d, tiles_n, n_tiles, stagger);
     return (int)hipGetLastError();
 }
 
@@ -330,7 +371,16 @@ int lvae_gemm_h2p_try(const lvae_gemm_desc* d, hipStream_t st, int force, int* r
         // serial split-K (FOLD): S slices of whole 32-deep stages, row-major fp32 / pre-split output with 16-B rows (what the reduce
         // kernel's epilogue function stores), 128 x 64 tiles (the running sum lives beside two accumulator sets)
         if ((d->K / 32) % d->ksplit || d->store != LVAE_ST_ROWMAJOR || (N & 3) || (d->ldo & 3) || (d->ldres & 3)) return 0;
-        *rc = launch_h2p<2, 1, 3, true>(d, st);
+        // up to one workgroup per CU: eight loader waves beside the four compute waves (above); more tiles: two workgroups per CU hide
+        // each other's DMA issue as before (tuning hook of tools/r6_fold_loaders.sh: LVAE_FOLD_LOADERS=0 / 1)
+#ifdef LVAE_EXPERIMENTAL_BUILD
+        static const int force = getenv("LVAE_FOLD_LOADERS") ? atoi(getenv("LVAE_FOLD_LOADERS")) : -1;
+#else
+        constexpr int force = -1;                                   // (the product library's launch paths read no environment)
+#endif
+        const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
+        const bool loaders = force >= 0 ? force != 0 : tiles <= lvae_cu_count();
+        *rc = loaders ? launch_h2p<2, 1, 3, true, 8>(d, st) : launch_h2p<2, 1, 3, true>(d, st);
         return 1;
     }
     int sel = force;

@@ -308,7 +308,11 @@ extern "C" int lvae_mlp_sk(const lvae_mlp_sk_desc* d, void* stream) {
     int rc = -22;
     if (C != 512) return -22;
     // 64-row workgroups where 32-row ones would be more than one round of the chip's CUs (tuning hook of tools/r6_mlp_sk_bench.py: LVAE_SK_NRB)
+#ifdef LVAE_EXPERIMENTAL_BUILD
     static const int force_nrb = getenv("LVAE_SK_NRB") ? atoi(getenv("LVAE_SK_NRB")) : 0;
+#else
+    constexpr int force_nrb = 0;                                    // (the product library's launch paths read no environment)
+#endif
     const bool two = force_nrb ? force_nrb == 2 : ((d->M + 31) / 32) * S2 > lvae_cu_count();
     if (CH == 128 && ngrp == 4) rc = two ? launch_sk<128, 4, 16, 4, 1, 2>(d, st) : launch_sk<128, 4, 16, 8, 2, 1>(d, st);
     else if (CH == 192 && ngrp == 3) rc = two ? launch_sk<192, 3, 16, 4, 1, 2>(d, st) : launch_sk<192, 3, 16, 8, 2, 1>(d, st);
