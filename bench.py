@@ -17,6 +17,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   fp32_mfma_mode_value -- the same workload with the exact fp32 MFMA arithmetic (a few extra steps after the timed region);
   config5_value -- BASELINE.json configs[4]: the reduced-precision mode (bf16 storage + MX-fp8 MFMA) on 4 x 1216x1216, Mpixels/s
                    (a few extra steps after the timed region; details in `config5`);
+  coder_workloads -- the step on three coder workloads x three operating points (round 6): 'typical' (the headline's streams: 99.5 % mode
+                   symbols), 'calibrated' (latents drawn from the model's own discretised prior: lossy-vae_amd/coder_workloads.py -- the
+                   statistics a trained model's streams have against its tables) and 'worst_case' (wide-profile weights on uniform-noise
+                   images: every table row, escapes), at the headline's batch, for ONE image and on config 5; per row enc / dec ms, Mpixels/s,
+                   mode hit rate, escape rate, single-stream decode ns per symbol;
+  other_sizes   -- the headline arithmetic at 4 x 1216x1216 and 2 x 1408x2048 (the other image sizes BASELINE.json names);
+  roofline.by_kernel -- the dominant family per kernel (launches per step, us per launch, GFLOP and algorithmic MB per launch, TFLOP/s);
   host_coder    -- rANS encode / decode rate of the native host coder on this step's symbols (Msymbols/s, threads);
   cpu_baseline  -- the CPU oracle (oracle/qarv_oracle.py: the reference's op graph on PyTorch CPU + the plain-C restatement of
                    CompressAI's coder, fed with arrays) on the node's PHYSICAL cores: cores/8 oracle processes of 8 torch threads each on
