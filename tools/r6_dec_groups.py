@@ -3,6 +3,9 @@ import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, 'lossy-vae_amd'))
 import torch
+from lvae import _native
+if os.environ.get('LVAE_LIB'):            # experimental build (tools/build_exp.sh)
+    _native.LIB_PATH = os.path.abspath(os.environ['LVAE_LIB'])
 import bench, coder_workloads as cw
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
