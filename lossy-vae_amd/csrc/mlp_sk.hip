@@ -53,13 +53,13 @@ template <int CH, int SPU, int NRB> struct SkRing {
     static constexpr int N = FIT < 7 ? FIT : 7;
 };
 
-// NRB = 32-row blocks per workgroup (1 or 2: with two, every streamed weight line serves 64 rows and a compute wave has two independent
-// accumulator chains per MFMA step)
+// NRB = 32-row blocks per workgroup (1 or 2).  With two, every streamed weight line serves 64 rows; the second row block is a second SET of
+// compute waves (wave = (row block, column block): registers per wave as with one), not a second accumulator chain per wave.
 template <int CH, int NGRP, int NQ1, int NL, int SPU, int NRB>
-__global__ __launch_bounds__(64 * (CH / 32 + NL), 1) void mlp_sk_kernel(const lvae_mlp_sk_desc d) {
+__global__ __launch_bounds__(64 * (NRB * CH / 32 + NL), 1) void mlp_sk_kernel(const lvae_mlp_sk_desc d) {
 #pragma clang fp contract(off)
     constexpr int RT = 32 * NRB;
-    constexpr int NW = CH / 32, KS = CH / 32, NBUF = SkRing<CH, SPU, NRB>::N;
+    constexpr int NWC = CH / 32, NW = NRB * NWC, KS = CH / 32, NBUF = SkRing<CH, SPU, NRB>::N;
     constexpr int ST1 = (RT + CH) * 128, ST2 = CH * 128;            // bytes of one k32 stage inside a slot: fc1 (32 y rows + CH W1 rows) / fc2 (CH W2 rows)
     constexpr int USZ = SkRing<CH, SPU, NRB>::USZ;                       // bytes of a ring slot
     constexpr int NG1 = RT / 8 + CH / 8, NG2 = CH / 8;                   // DMA pieces of one stage
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64 * (CH / 32 + NL), 1) void mlp_sk_kernel(const lv
         return;
     }
 
-    // ---------------------------------------------------------------------- compute waves
+    // ---------------------------------------------------------------------- compute waves: wave = (row block rb, column block cb)
+    const int rb = wave / NWC, cb = wave - rb * NWC;
     const int li = lane & 31, lh = lane >> 5, lj = li & 3;
     const int per1 = NQ1 / S1;
     // fragment addresses: chunk (plane p, k16 step tt, lane half lh) = 4 p + 2 tt + lh of the lane's row, at ((chunk ^ xr) << 4)
@@ -139,149 +140,121 @@ __global__ __launch_bounds__(64 * (CH / 32 + NL), 1) void mlp_sk_kernel(const lv
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) fo[pt] = (unsigned)(((4 * (pt >> 1) + 2 * (pt & 1) + lh) ^ xr) << 4);
     const unsigned ring_a = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)ring;
-    const unsigned a_row = ring_a + li * 128, b1_row = ring_a + (RT + wave * 32 + li) * 128, b2_row = ring_a + (wave * 32 + li) * 128;
-    const unsigned h_row = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)hid_lds + li * 128;
+    const unsigned a_row = ring_a + (rb * 32 + li) * 128, b1_row = ring_a + (RT + cb * 32 + li) * 128, b2_row = ring_a + (cb * 32 + li) * 128;
+    const unsigned h_row = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)hid_lds + (rb * 32 + li) * 128;
 
-    // fc1: P[RT x 32 of this wave] = y W1c^T, S1 slices folded in order
-    f32x16 accH[NRB], accX[NRB], tot[NRB];
+    // fc1: P[32 x 32 of this wave] = y W1c^T, S1 slices folded in order
+    f32x16 accH, accX, tot;
 #pragma unroll
-    for (int a = 0; a < NRB; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accH[a][r] = 0.f; accX[a][r] = 0.f; tot[a][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { accH[r] = 0.f; accX[r] = 0.f; tot[r] = 0.f; }
     int in_slice = 0, slice = 0, buf = 0;
     for (int un = 0; un < NU1; ++un) {
         asm volatile("s_barrier" ::: "memory");
         SK_FENCE();
 #pragma unroll
         for (int st = 0; st < SPU; ++st) {
-            f16x8 af[NRB][2][2], bf[2][2];                          // [row block][tt][plane]
+            f16x8 af[2][2], bf[2][2];                               // [tt][plane]
             const unsigned ua = a_row + buf * USZ + st * ST1, ub = b1_row + buf * USZ + st * ST1;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) { SK_DSR(af[a][tt][0], ua + a * 4096 + fo[0 + tt]); SK_DSR(af[a][tt][1], ua + a * 4096 + fo[2 + tt]); }
+                SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
                 SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                if constexpr (NRB == 1) {
-                    if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-                } else {
-                    if (tt == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[NRB - 1][0][0]), "+v"(af[NRB - 1][0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(af[NRB - 1][1][0]), "+v"(af[NRB - 1][1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-                }
+                if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
                 SK_FENCE();
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) accX[a] = SK_MFMA(af[a][tt][1], bf[tt][0], accX[a]);
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) accX[a] = SK_MFMA(af[a][tt][0], bf[tt][1], accX[a]);
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) accH[a] = SK_MFMA(af[a][tt][0], bf[tt][0], accH[a]);
+                accX = SK_MFMA(af[tt][1], bf[tt][0], accX);
+                accX = SK_MFMA(af[tt][0], bf[tt][1], accX);
+                accH = SK_MFMA(af[tt][0], bf[tt][0], accH);
                 SK_FENCE();
             }
             if (++in_slice == per1) {                               // end of a K slice of fc1: the partial sum as the parallel form stores it
                 in_slice = 0;
 #pragma unroll
-                for (int a = 0; a < NRB; ++a)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float pr = __builtin_fmaf(accX[a][r], 1.0f / 2048.0f, accH[a][r]);
-                        if (S1 > 1) pr = pr + 0.0f;                 // (the slab store's "+ bias" with no bias: -0 -> +0)
-                        tot[a][r] = slice == 0 ? pr : tot[a][r] + pr;
-                        accH[a][r] = 0.f; accX[a][r] = 0.f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    float pr = __builtin_fmaf(accX[r], 1.0f / 2048.0f, accH[r]);
+                    if (S1 > 1) pr = pr + 0.0f;                     // (the slab store's "+ bias" with no bias: -0 -> +0)
+                    tot[r] = slice == 0 ? pr : tot[r] + pr;
+                    accH[r] = 0.f; accX[r] = 0.f;
+                }
                 ++slice;
             }
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
     // + bias -> GELU -> f16x2 split -> the hidden tile in LDS: [KS][RT rows][128 B], stage ks = this wave's 32 columns; rows 4 lh + 8 g + lj
-    // of each row block after the quad transpose
+    // of its row block after the quad transpose
     {
-        const f32x4 vb = *(const f32x4*)(d.b1 + c * CH + wave * 32 + (li & ~3));
+        const f32x4 vb = *(const f32x4*)(d.b1 + c * CH + cb * 32 + (li & ~3));
         const int col32 = li & ~3;
 #pragma unroll
-        for (int a = 0; a < NRB; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v0 = tot[a][4 * g + 0], v1 = tot[a][4 * g + 1], v2 = tot[a][4 * g + 2], v3 = tot[a][4 * g + 3];
-                quad_transpose(v0, v1, v2, v3, lj);
-                v0 += vb[0]; v1 += vb[1]; v2 += vb[2]; v3 += vb[3];
-                gelu_erf4(v0, v1, v2, v3);
-                unsigned h0, l0, h1, l1;
-                split_pair_h2(v0, v1, h0, l0);
-                split_pair_h2(v2, v3, h1, l1);
-                const int r = 4 * lh + 8 * g + lj;
-                char* q = hid_lds + (wave * RT + a * 32 + r) * 128 + ((col32 & 4) << 1);
-                const int sw = (r >> 1) & 7;
-                *(u32x2_t*)(q + ((((col32 >> 3)) ^ sw) << 4)) = (u32x2_t){h0, h1};
-                *(u32x2_t*)(q + (((4 + (col32 >> 3)) ^ sw) << 4)) = (u32x2_t){l0, l1};
-            }
+        for (int g = 0; g < 4; ++g) {
+            float v0 = tot[4 * g + 0], v1 = tot[4 * g + 1], v2 = tot[4 * g + 2], v3 = tot[4 * g + 3];
+            quad_transpose(v0, v1, v2, v3, lj);
+            v0 += vb[0]; v1 += vb[1]; v2 += vb[2]; v3 += vb[3];
+            gelu_erf4(v0, v1, v2, v3);
+            unsigned h0, l0, h1, l1;
+            split_pair_h2(v0, v1, h0, l0);
+            split_pair_h2(v2, v3, h1, l1);
+            const int r = 4 * lh + 8 * g + lj;
+            char* q = hid_lds + (cb * RT + rb * 32 + r) * 128 + ((col32 & 4) << 1);
+            const int sw = (r >> 1) & 7;
+            *(u32x2_t*)(q + ((((col32 >> 3)) ^ sw) << 4)) = (u32x2_t){h0, h1};
+            *(u32x2_t*)(q + (((4 + (col32 >> 3)) ^ sw) << 4)) = (u32x2_t){l0, l1};
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // hidden tile complete (the loaders join this barrier too)
     SK_FENCE();
 
-    // fc2: O[RT x C] partial over k = the CH hidden columns of slice c, one group of CH output columns after the other (a group's
-    // accumulators live only while its units run: its partial sums leave for plane c of the workspace -- fma(X, 2^-11, H) + 0.0f,
+    // fc2: O[32 x C of this wave's row block] partial over k = the CH hidden columns of slice c, one group of CH output columns after the other
+    // (a group's accumulators live only while its units run: its partial sums leave for plane c of the workspace -- fma(X, 2^-11, H) + 0.0f,
     // row-major [M][C], what gemm_h2_kernel's slice c stores (gemm_finish, SLAB) -- as soon as its last unit is done)
     float* const plane = d.ws + (long)c * d.M * C;
-    f32x16 oH[NRB], oX[NRB];
+    f32x16 oH, oX;
 #pragma unroll
     for (int u = 0; u < NU2; ++u) {
         const int grp = u / (KS / SPU), ks0 = (u % (KS / SPU)) * SPU, ubuf = (NU1 + u) % NBUF;
         if (ks0 == 0) {
 #pragma unroll
-            for (int a = 0; a < NRB; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { oH[a][r] = 0.f; oX[a][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { oH[r] = 0.f; oX[r] = 0.f; }
         }
         asm volatile("s_barrier" ::: "memory");
         SK_FENCE();
 #pragma unroll
         for (int st = 0; st < SPU; ++st) {
-            f16x8 af[NRB][2][2], bf[2][2];
+            f16x8 af[2][2], bf[2][2];
             const unsigned ua = h_row + (ks0 + st) * RT * 128, ub = b2_row + ubuf * USZ + st * ST2;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) { SK_DSR(af[a][tt][0], ua + a * 4096 + fo[0 + tt]); SK_DSR(af[a][tt][1], ua + a * 4096 + fo[2 + tt]); }
+                SK_DSR(af[tt][0], ua + fo[0 + tt]); SK_DSR(af[tt][1], ua + fo[2 + tt]);
                 SK_DSR(bf[tt][0], ub + fo[0 + tt]); SK_DSR(bf[tt][1], ub + fo[2 + tt]);
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                if constexpr (NRB == 1) {
-                    if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-                } else {
-                    if (tt == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[NRB - 1][0][0]), "+v"(af[NRB - 1][0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(af[NRB - 1][1][0]), "+v"(af[NRB - 1][1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
-                }
+                if (tt == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1]));
                 SK_FENCE();
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) oX[a] = SK_MFMA(af[a][tt][1], bf[tt][0], oX[a]);
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) oX[a] = SK_MFMA(af[a][tt][0], bf[tt][1], oX[a]);
-#pragma unroll
-                for (int a = 0; a < NRB; ++a) oH[a] = SK_MFMA(af[a][tt][0], bf[tt][0], oH[a]);
+                oX = SK_MFMA(af[tt][1], bf[tt][0], oX);
+                oX = SK_MFMA(af[tt][0], bf[tt][1], oX);
+                oH = SK_MFMA(af[tt][0], bf[tt][0], oH);
                 SK_FENCE();
             }
         }
         if (ks0 + SPU == KS) {                                      // the group's last unit
-            const int n0 = grp * CH + wave * 32;
+            const int n0 = grp * CH + cb * 32;
             if (n0 < C) {                                           // uniform: the last group of a C that is no multiple of CH
 #pragma unroll
-                for (int a = 0; a < NRB; ++a)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0 = __builtin_fmaf(oX[a][4 * q + 0], 1.0f / 2048.0f, oH[a][4 * q + 0]) + 0.0f;
-                        float v1 = __builtin_fmaf(oX[a][4 * q + 1], 1.0f / 2048.0f, oH[a][4 * q + 1]) + 0.0f;
-                        float v2 = __builtin_fmaf(oX[a][4 * q + 2], 1.0f / 2048.0f, oH[a][4 * q + 2]) + 0.0f;
-                        float v3 = __builtin_fmaf(oX[a][4 * q + 3], 1.0f / 2048.0f, oH[a][4 * q + 3]) + 0.0f;
-                        quad_transpose(v0, v1, v2, v3, lj);
-                        const int row = m0 + a * 32 + 4 * lh + 8 * q + lj;
-                        if (row < d.M) *(f32x4*)(plane + (long)row * C + n0 + (li & ~3)) = (f32x4){v0, v1, v2, v3};
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = __builtin_fmaf(oX[4 * q + 0], 1.0f / 2048.0f, oH[4 * q + 0]) + 0.0f;
+                    float v1 = __builtin_fmaf(oX[4 * q + 1], 1.0f / 2048.0f, oH[4 * q + 1]) + 0.0f;
+                    float v2 = __builtin_fmaf(oX[4 * q + 2], 1.0f / 2048.0f, oH[4 * q + 2]) + 0.0f;
+                    float v3 = __builtin_fmaf(oX[4 * q + 3], 1.0f / 2048.0f, oH[4 * q + 3]) + 0.0f;
+                    quad_transpose(v0, v1, v2, v3, lj);
+                    const int row = m0 + rb * 32 + 4 * lh + 8 * q + lj;
+                    if (row < d.M) *(f32x4*)(plane + (long)row * C + n0 + (li & ~3)) = (f32x4){v0, v1, v2, v3};
+                }
             }
         }
     }
@@ -293,7 +266,7 @@ int launch_sk(const lvae_mlp_sk_desc* d, hipStream_t st) {
     static LdsAttr attr;
     if (const int ae = attr.ensure((const void*)mlp_sk_kernel<CH, NGRP, NQ1, NL, SPU, NRB>, LDS)) return ae;
     const int row_tiles = (d->M + 32 * NRB - 1) / (32 * NRB);
-    hipLaunchKernelGGL((mlp_sk_kernel<CH, NGRP, NQ1, NL, SPU, NRB>), dim3(row_tiles * d->S2), dim3(64 * (CH / 32 + NL)), LDS, st, *d);
+    hipLaunchKernelGGL((mlp_sk_kernel<CH, NGRP, NQ1, NL, SPU, NRB>), dim3(row_tiles * d->S2), dim3(64 * (NRB * CH / 32 + NL)), LDS, st, *d);
     return (int)hipGetLastError();
 }
 
@@ -314,8 +287,8 @@ extern "C" int lvae_mlp_sk(const lvae_mlp_sk_desc* d, void* stream) {
     constexpr int force_nrb = 0;                                    // (the product library's launch paths read no environment)
 #endif
     const bool two = force_nrb ? force_nrb == 2 : ((d->M + 31) / 32) * S2 > lvae_cu_count();
-    if (CH == 128 && ngrp == 4) rc = two ? launch_sk<128, 4, 16, 4, 1, 2>(d, st) : launch_sk<128, 4, 16, 8, 2, 1>(d, st);
-    else if (CH == 192 && ngrp == 3) rc = two ? launch_sk<192, 3, 16, 4, 1, 2>(d, st) : launch_sk<192, 3, 16, 8, 2, 1>(d, st);
+    if (CH == 128 && ngrp == 4) rc = two ? launch_sk<128, 4, 16, 8, 1, 2>(d, st) : launch_sk<128, 4, 16, 8, 2, 1>(d, st);
+    else if (CH == 192 && ngrp == 3) rc = launch_sk<192, 3, 16, 8, 2, 1>(d, st);      // (two row blocks would be 20 waves)
     else if (CH == 256 && ngrp == 2) rc = launch_sk<256, 2, 16, 4, 1, 1>(d, st);
     if (rc) return rc;
     // the second pass of the parallel split-K form, unchanged: out = res + gamma * (sum over the S2 planes in slice order + bias)
