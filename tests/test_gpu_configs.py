@@ -429,7 +429,7 @@ def test_bench_line_carries_a_measured_roofline(offline_home, tmp_path):
     duration, 0 < frac < 1 -- also now that the product path runs a pipeline group's loop natively (no per-launch hook: the
     roofline pass replays launch by launch), and value = pixels / time."""
     out = _run([os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--fp32-steps', '0',
-                '--config5-steps', '0', '--roofline-steps', '1'], offline_home, tmp_path)
+                '--config5-steps', '0', '--roofline-steps', '1', '--coder-steps', '2', '--size-steps', '1', '--qres-steps', '0'], offline_home, tmp_path)
     j = [json.loads(l) for l in out.splitlines() if l.startswith('{')][0]
     r = j['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['launches'] > 100 and r['avg_launch_us'] > 5
@@ -440,6 +440,20 @@ def test_bench_line_carries_a_measured_roofline(offline_home, tmp_path):
     assert 'groups of 4, 4 images' in r['measured_over'], r['measured_over']
     assert abs(j['value'] - 8 * 512 * 768 / (j['ms_per_step'] * 1e3)) < 0.01 * j['value']
     assert abs(j['ms_per_step'] - j['enc_ms_per_step'] - j['dec_ms_per_step']) < 0.05 * j['ms_per_step']
+    # the family per kernel (round 6): the rows add up to the family
+    bk = r['by_kernel']
+    assert sum(v['launches_per_step'] for v in bk.values()) == r['launches_per_step'] and any(k.startswith('mlp_sk') for k in bk), bk
+    # the coder workloads: typical / calibrated / worst case at the headline's batch and for one image; calibrated
+    # streams obey their tables (coded size == table entropy) and are NOT mostly modes; the other image sizes of BASELINE.json
+    cw = j['coder_workloads']
+    for op in ('b8_512x768', 'b1_512x768'):
+        for kind in ('typical', 'calibrated', 'worst_case'):
+            row = cw[op][kind]
+            assert 'error' not in row and row['value'] > 0 and row['dec_ms_per_step'] > 0 and row['dec_ns_per_symbol_single_stream'] > 0, (op, kind, row)
+        assert abs(cw[op]['calibrated']['coded_over_table_entropy'] - 1) < 0.02 and cw[op]['calibrated']['mode_hit_rate'] < 0.6
+        assert cw[op]['typical']['mode_hit_rate'] > 0.9 and cw[op]['worst_case']['escape_rate'] > 0.05
+    assert 'error' not in cw and set(j['other_sizes']) == {'b4_1216x1216', 'b2_1408x2048'}
+    assert all('error' not in v and v['value'] > 0 for v in j['other_sizes'].values()), j['other_sizes']
 
 
 # ------------------------------------------------------------------------------------------------------------------ H2, f2
