@@ -350,26 +350,32 @@ def coder_workload_rows(model, dev, ims, precision, steps, kind_rows=('typical',
     prior: lossy-vae_amd/coder_workloads.py).  Per row: enc / dec ms per step (the bench's step: compress_batch, sync, decompress_batch,
     sync -- for the calibrated row the encode is that of the sampled reconstruction, the decode that of the calibrated strings), enc+dec
     Mpixels/s, the streams' mode hit rate / escape rate / bits per symbol, single-stream decode ns per symbol of image 0's largest latent
-    block (bytes re-encoded == bytes decoded is asserted on it)."""
+    block (bytes re-encoded == bytes decoded is asserted on it).  enc / dec ms are the median step of the row."""
     import coder_workloads as cw
     B, _, H, W = ims.shape
     groups = model.pipeline_groups
 
+    # (these side rows report the MEDIAN step: with 8-16 steps one scheduling hiccup would otherwise move a row by several per cent;
+    #  the headline above is the mean over its timed region, as the contract says)
     def t_enc(x):
         for _ in range(2):
             model.compress_batch(x); torch.cuda.synchronize(dev)
-        t0 = time.time()
+        ts = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             s = model.compress_batch(x); torch.cuda.synchronize(dev)
-        return (time.time() - t0) / steps * 1e3, s
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, s
 
     def t_dec(strings):
         for _ in range(2):
             model.decompress_batch(strings); torch.cuda.synchronize(dev)
-        t0 = time.time()
+        ts = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             o = model.decompress_batch(strings); torch.cuda.synchronize(dev)
-        return (time.time() - t0) / steps * 1e3, o
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, o
 
     rows = {}
     for kind in kind_rows:
@@ -466,7 +472,7 @@ def main():
     ap.add_argument('--size-steps', type=int, default=4,
                     help='extra steps at the other image sizes BASELINE.json names, headline arithmetic -> other_sizes: 4 x 1216x1216 (Tecnick, padded) and '
                          '2 x 1408x2048 (CLIC-sized: config 4 shards such images over the GPUs, this is the per-GPU rate) (0 = skip)')
-    ap.add_argument('--coder-steps', type=int, default=8,
+    ap.add_argument('--coder-steps', type=int, default=10,
                     help='extra steps per coder-workload row after the timed region -> coder_workloads: typical / calibrated (latents drawn from the '
                          "model's own prior) / worst_case (wide-profile weights on uniform-noise images) x (batch of 8, single image, config 5) (0 = skip)")
     args = ap.parse_args()
