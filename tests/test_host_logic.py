@@ -210,6 +210,17 @@ def test_small_map_fused_mlp_rule_keeps_the_split_k_contract():
         S1 = auto_ksplit(rows, hid, C, 0, hid, 0, 4); S2 = auto_ksplit(rows, C, hid, 0, C, C, 4)
         assert plan(1).mlp_sk_ok(C, hid, k, rows, rows) == (S1, S2)
         assert _native.lib().lvae_mlp_sk_supported(C, hid, S1, S2) == 1
+    # argument errors come back as -22 before anything is launched (no GPU needed): a shape without an instance, no split-K, a NULL operand
+    import ctypes
+    d = _native.MlpSkDesc()
+    for f in ('y', 'w1', 'b1', 'w2', 'b2', 'gamma', 'res', 'out', 'ws'):
+        setattr(d, f, 4096)
+    d.M, d.C, d.hid, d.S1, d.S2 = 96, 256, 448, 2, 2
+    assert _native.lib().lvae_mlp_sk(ctypes.byref(d), None) == -22 and _native.lib().lvae_mlp_sk_supported(256, 448, 2, 2) == 0
+    d.C, d.hid, d.S1, d.S2 = 512, 2048, 4, 1
+    assert _native.lib().lvae_mlp_sk(ctypes.byref(d), None) == -22
+    d.S2, d.ws = 16, None
+    assert _native.lib().lvae_mlp_sk(ctypes.byref(d), None) == -22
 
 
 def test_numa_pinning_groups_ranks_by_host(monkeypatch):
