@@ -190,6 +190,10 @@ typedef struct {
                                              [K/64][R][2] bytes (lvae.models.base.pack_mxfp8_q8): a_h2 = 1: A0 (and Wt16) are Q8 buffers,
                                              written by lvae_dwconv_ln_q8 / a GEMM with out_h2 (csrc/gemm_q8.hip: no quantiser in the main
                                              loop); out_h2 = 1: the result (EPI_BIAS / EPI_BIAS_GELU, N % 64 == 0, ldo = N) is stored as Q8 */
+    int  defer_reduce;                    /* ksplit > 1, parallel form only: 1 = the launch writes the S partial-sum planes to `ws` and does NOT
+                                             run the reduce pass (no bias / epilogue is applied): a consumer that reads the planes itself
+                                             finishes the job -- lvae_prior_index_sk_f32 sums them in slice order, adds the bias and goes on to
+                                             the scale indexes: one launch less per latent block, the bits of the two-launch form (round 6) */
 } lvae_gemm_desc;
 int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream);
 
@@ -233,7 +237,7 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 enum {
     LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_DWCONV_LN_Q8, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
     LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
-    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_MLP_SK, LVAE_OP_ORDER
+    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_MLP_SK, LVAE_OP_PRIOR_INDEX_SK, LVAE_OP_ORDER
 };
 typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
 #define LVAE_TRACE_MAGIC 1985229328.0      /* lvae_decode_blocks: seconds[1] of a timeline request */
@@ -346,6 +350,11 @@ int lvae_gemv_f32(const float* Wt, const float* b, const float* x, float* y, int
 int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
                          float scale_bound, int B, int HW, int z, int* status, void* stream);
 /* status (optional): LVAE_STATUS_NONFINITE_PRIOR is OR-ed in when a mean or log-scale parameter is NaN / inf (see "status word"). */
+/* The same behind a split-K `prior` GEMM whose reduce pass was deferred (lvae_gemm_desc.defer_reduce): prm[m][c] = ((ws[0] + ws[1]) + ...
+ * + ws[S-1])[m][c] + bias[c] -- planes of [B*HW][2z] floats, summed in slice order like splitk_reduce does -- is written (other consumers
+ * read it: lvae_gaussian_nll_f32, lvae_prior_sample_f32) and indexed in ONE launch. */
+int lvae_prior_index_sk_f32(const float* ws, int S, const float* bias, float* prm, float* pm, uint8_t* idx, const float* scale_table,
+                            int n_scales, float scale_bound, int B, int HW, int z, int* status, void* stream);
 
 /* GaussianConditional.quantize (qarv/model.py:107-108): sym = int32(rint_half_even(qm - pm)) in NCHW raster order
  * per image, zhat = float(sym) + pm in NHWC (row stride ldz, see below). */

@@ -743,7 +743,7 @@ extern "C" int lvae_gemm_f32(const lvae_gemm_desc* d, void* stream) {
             return lvae_gemm_f32(&d2, stream);
         }
         const int rc = gemm_dispatch(d, st, x3v2, x3v2_tn);
-        if (rc || d->cnt) return rc;                                  // cnt: reduced in place by each tile's last-arriving slice
+        if (rc || d->cnt || d->defer_reduce) return rc;               // cnt: reduced in place by each tile's last-arriving slice; defer_reduce: by the consumer
         const long n = (long)d->M * (d->N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d, S);
         return (int)hipGetLastError();

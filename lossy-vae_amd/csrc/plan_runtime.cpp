@@ -72,6 +72,10 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
             case LVAE_OP_LOSSLESS_OUTPUT: rc = lvae_lossless_output_f32((const int32_t*)p[0], (const float*)p[1], (float*)p[2], i[0], (int*)p[3], st); break;
             case LVAE_OP_MLP_H2F: rc = lvae_mlp_h2f((const lvae_mlp_desc*)p[0], st); break;
             case LVAE_OP_MLP_SK: rc = lvae_mlp_sk((const lvae_mlp_sk_desc*)p[0], st); break;
+            case LVAE_OP_PRIOR_INDEX_SK:
+                rc = lvae_prior_index_sk_f32((const float*)p[0], (int)i[0], (const float*)p[1], (float*)p[2], (float*)p[3], (uint8_t*)p[4], (const float*)p[5],
+                                             (int)i[1], (float)f[0], (int)i[2], (int)i[3], (int)i[4], (int*)p[6], st);
+                break;
             case LVAE_OP_ORDER:      // i[0] != 0: the side stream waits for the main stream (fork); else the main stream for the side stream (join)
                 rc = i[0] ? lvae_stream_order(stream, side_stream, p[0]) : lvae_stream_order(side_stream, stream, p[0]);
                 break;

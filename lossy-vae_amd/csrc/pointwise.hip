@@ -409,9 +409,15 @@ __global__ void prior_sample_kernel(const float* __restrict__ prm, float* __rest
 // raster in runs of 64 consecutive entries per channel.  Per element the arithmetic is unchanged (same bits).
 constexpr int CT_PIX = 64, CT_CH = 16, CT_LD = CT_PIX + 1;      // (16 channels per workgroup: 4 elements per thread -- enough workgroups to fill the chip on the stride-16 maps)
 
-__global__ __launch_bounds__(256) void prior_index_kernel(const float* __restrict__ prm, float* __restrict__ pm, uint8_t* __restrict__ idx,
+// SK: the prior parameters are first formed from the S partial-sum planes of a split-K GEMM whose reduce pass was deferred (ws, plane =
+// floats per plane, bias): ((ws[0] + ws[1]) + ...) + bias in slice order -- splitk_reduce_chunk's operations, so the bits of the reduce
+// launch this replaces -- and written to prm for the other consumers.
+template <bool SK>
+__global__ __launch_bounds__(256) void prior_index_kernel(const float* __restrict__ prm_in, float* __restrict__ pm, uint8_t* __restrict__ idx,
                                                           const float* __restrict__ table, int n_scales, float bound, int HW, int z,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, const float* __restrict__ ws, int S, long plane,
+                                                          const float* __restrict__ bias, float* __restrict__ prm_out) {
+#pragma clang fp contract(off)
     __shared__ int tile[CT_CH * CT_LD];
     __shared__ float tab[256];                         // the scale table (n_scales <= 256: checked by the launcher): the binary search below is
     if ((int)threadIdx.x < n_scales) tab[threadIdx.x] = table[threadIdx.x];     // six DEPENDENT loads per element -- from LDS, not from L2
@@ -424,8 +430,17 @@ __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restric
         for (int i = threadIdx.x; i < np * zc; i += 256) {
             const int pl = i / zc, c = c0 + (i - pl * zc);
             const long m = m0 + pl;
-            const float mean = prm[m * 2 * z + c];
-            const float lv = prm[m * 2 * z + z + c];
+            float mean, lv;
+            if constexpr (SK) {
+                const float* w = ws + m * 2 * z + c;
+                mean = w[0]; lv = w[z];
+                for (int sl = 1; sl < S; ++sl) { mean += w[sl * plane]; lv += w[sl * plane + z]; }
+                mean += bias[c]; lv += bias[z + c];
+                prm_out[m * 2 * z + c] = mean; prm_out[m * 2 * z + z + c] = lv;
+            } else {
+                mean = prm_in[m * 2 * z + c];
+                lv = prm_in[m * 2 * z + z + c];
+            }
             // a NaN / inf prior parameter (an fp16 overflow of the f16x2 arithmetic upstream, include/lvae_hip.h "status word") would become
             // index 0 / 63 and a NaN mean silently: report it (one atomic per wave that saw one)
             if (status && !(fabsf(mean) <= 3.4028234664e38f && fabsf(lv) <= 3.4028234664e38f)) atomicOr(status, LVAE_STATUS_NONFINITE_PRIOR);
@@ -697,8 +712,16 @@ extern "C" int lvae_gemv_f32(const float* Wt, const float* b, const float* x, fl
 extern "C" int lvae_prior_index_f32(const float* prm, float* pm, uint8_t* idx, const float* scale_table, int n_scales,
                                     float scale_bound, int B, int HW, int z, int* status, void* stream) {
     if (!prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || B > 65535 || HW <= 0 || z <= 0) return -22;
-    hipLaunchKernelGGL(prior_index_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((z + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, pm,
-                       idx, scale_table, n_scales, scale_bound, HW, z, status);
+    hipLaunchKernelGGL(prior_index_kernel<false>, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((z + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, prm, pm,
+                       idx, scale_table, n_scales, scale_bound, HW, z, status, (const float*)nullptr, 0, 0L, (const float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_prior_index_sk_f32(const float* ws, int S, const float* bias, float* prm, float* pm, uint8_t* idx, const float* scale_table,
+                                       int n_scales, float scale_bound, int B, int HW, int z, int* status, void* stream) {
+    if (!ws || S < 2 || !bias || !prm || !pm || !idx || !scale_table || n_scales < 2 || n_scales > 256 || B <= 0 || B > 65535 || HW <= 0 || z <= 0) return -22;
+    hipLaunchKernelGGL(prior_index_kernel<true>, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((z + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, pm, idx, scale_table, n_scales, scale_bound, HW, z, status, ws, S, (long)B * HW * 2 * z, bias, prm);
     return (int)hipGetLastError();
 }
 
@@ -822,5 +845,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 22; }
+extern "C" int lvae_abi_version(void) { return 23; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
         ('a_mode', C.c_int), ('epi', C.c_int), ('store', C.c_int), ('r', C.c_int),
         ('a_gelu', C.c_int), ('prec', C.c_int), ('Wt16', C.c_void_p), ('cfg', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('a_bf16', C.c_int), ('out_bf16', C.c_int), ('cnt', C.c_void_p),
-        ('status', C.c_void_p), ('a_h2', C.c_int), ('out_h2', C.c_int),
+        ('status', C.c_void_p), ('a_h2', C.c_int), ('out_h2', C.c_int), ('defer_reduce', C.c_int),
     ]
 
 
@@ -64,7 +64,7 @@ class EncBlock(C.Structure):
 OP_KINDS = {name: k + 1 for k, name in enumerate([
     'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_dwconv_ln_q8', 'lvae_stem_f32', 'lvae_stem_bf16',
     'lvae_bias_expand_f32', 'lvae_bias_expand_bf16', 'lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32',
-    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f', 'lvae_mlp_sk'])}
+    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f', 'lvae_mlp_sk', 'lvae_prior_index_sk_f32'])}
 OP_ORDER = len(OP_KINDS) + 1
 
 TRACE_MAGIC = 1985229328.0       # LVAE_TRACE_MAGIC
@@ -101,6 +101,7 @@ SIGNATURES = {
     'lvae_bias_expand_bf16': (_i, [_vp, _vp, _l, _i, _vp]),
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
+    'lvae_prior_index_sk_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
     'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_lossless_params_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),

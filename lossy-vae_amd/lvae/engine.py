@@ -308,7 +308,10 @@ class Plan:
     def gemm(self, *, A0, K0, M, N, Wt, bias, out, lda0=None, A1=None, K1=0, lda1=0, ldw=None, ldo=None,
              gamma=None, res=None, ldres=0, a_mode=_native.A_PLAIN, epi=_native.EPI_BIAS, store=_native.ST_ROWMAJOR,
              r=0, H=0, W=0, K=None, a_gelu=0, Wt16=None, exact=False, ksplit=None, a_bf16=None, out_bf16=None, a_h2=False,
-             out_h2=False, label='gemm'):
+             out_h2=False, defer_reduce=False, label='gemm'):
+        """Record one lvae_gemm_f32 launch.  defer_reduce=True (a GEMM with a plain bias epilogue whose consumer can sum split-K planes
+        itself: the prior head in front of lvae_prior_index_sk_f32): when the launch runs parallel split-K, its reduce pass is left to the
+        consumer and (workspace address, S) is returned; otherwise -- no split-K, or a form that has no planes -- None, and `out` is final."""
         if K is None:
             K = K0 + K1
         if a_h2:               # both operands pre-converted (f16x2: H2K32 planes; fp8 mode: Q8): mlp_h2p_ok() / mlp_q8_ok() said so
@@ -357,15 +360,20 @@ class Plan:
             ksplit = 1
         if ksplit is None:
             ksplit = auto_ksplit(M // max(1, getattr(self, 'B', 1)), N, K, store, d.ldo, ldres, d.prec)
+        deferred = None
         if ksplit > 1 and a_h2:
             d.ksplit = ksplit                                      # serial form: no workspace, no reduce launch
+        elif ksplit > 1 and defer_reduce and epi == _native.EPI_BIAS and store == _native.ST_ROWMAJOR and d.ldo == N and bias:
+            # (a workspace of its own name: the consumer launch follows at once, on the same stream)
+            d.ksplit, d.ws, d.defer_reduce = ksplit, self.buf(self.sname('deferred_ws'), ksplit * M * N).data_ptr(), 1
+            deferred = (d.ws, ksplit)
         elif ksplit > 1:
             d.ksplit, d.ws = ksplit, self.buf(self.sname('splitk_ws'), ksplit * M * N).data_ptr()
             # In-kernel slice reduction (lvae_gemm_desc.cnt: a tile's last-arriving slice workgroup sums the S slabs in place of the
             # second launch) is taken only when the slabs of one tile are small: the last arriver reads S x tile bytes ALONE at the
             # cross-XCD rate (~65 GB/s per workgroup), so with the 128 x 128..192 tiles of the MLP layers (64-98 KB x S) it costs more
             # than the reduce launch it removes (measured on MI355X: 105 -> 100 Mpixels/s at B = 8, 12.1 -> 13.3 ms at B = 1).
-            if ksplit * 128 * min(N, 192) * 4 <= INKERNEL_REDUCE_MAX_BYTES:
+            if not deferred and ksplit * 128 * min(N, 192) * 4 <= INKERNEL_REDUCE_MAX_BYTES:
                 n_cnt = ((M + 63) // 64) * ((N + 31) // 32)
                 cname = self.sname('splitk_cnt')
                 cnt = self.bufs.get(cname)
@@ -380,6 +388,7 @@ class Plan:
         self.keep.append(d)
         self.flops += 2 * M * N * K
         self.add(self.lib.lvae_gemm_f32, (ctypes.byref(d),), label)
+        return deferred
 
     # (C, hidden) block shapes whose MLP runs as ONE launch (csrc/mlp_h2c.hip: hidden dimension walked in chunks, weights streamed): the
     # decoder's and the encoder's stride-4 blocks

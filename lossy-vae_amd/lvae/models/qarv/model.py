@@ -288,8 +288,9 @@ class _NetPlan(Plan):
             self.fork(p + '.fork_prior')
             self.side_begin()
         prm = self.buf('prm', M * 2 * z)
-        self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
-                  out=prm.data_ptr(), out_bf16=0, label=p + '.prior')
+        # (split-K launches leave their reduce pass to the index kernel: one launch less per latent block on both chains, same bits)
+        planes = self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
+                           out=prm.data_ptr(), out_bf16=0, defer_reduce=(self.prec != 3), label=p + '.prior')
         pm = self.new(M * z)
         self.pm_bufs.append(pm)
         self.prm_ptrs.append(prm.data_ptr())
@@ -297,8 +298,13 @@ class _NetPlan(Plan):
         ioff = sum(s[0] * s[1] for s in self.lat_shapes) * B
         self.lat_shapes.append((z, H * W))
         self.idx_off.append(ioff)
-        self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
-                                            pk.scale_table.numel(), pk.scale_bound, B, H * W, z, self.status_ptr()), p + '.prior_index')
+        if planes is not None:
+            self.add(lib.lvae_prior_index_sk_f32, (planes[0], planes[1], pk.p(p + '.prior.b'), prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff),
+                                                   pk.scale_table.data_ptr(), pk.scale_table.numel(), pk.scale_bound, B, H * W, z, self.status_ptr()),
+                     p + '.prior_index')
+        else:
+            self.add(lib.lvae_prior_index_f32, (prm.data_ptr(), pm.data_ptr(), ptr(self.idx_all, ioff), pk.scale_table.data_ptr(),
+                                                pk.scale_table.numel(), pk.scale_bound, B, H * W, z, self.status_ptr()), p + '.prior_index')
         self.side_end()
         return pm, ioff
 

@@ -307,6 +307,59 @@ def test_gemv(L):
         assert (y.double() - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('B,HW,z,S', [(3, 35, 32, 4), (1, 96, 32, 4), (2, 1536, 96, 3), (4, 6144, 8, 2), (1, 70, 16, 7)])
+def test_prior_index_behind_a_deferred_split_k_reduce(L, B, HW, z, S):
+    """lvae_prior_index_sk_f32 (round 6): the prior parameters formed from the S partial-sum planes of a split-K GEMM whose reduce pass was
+    deferred -- ((ws[0] + ws[1]) + ...) + bias in slice order -- then indexed, against the two-launch form: the sum done by torch in the
+    same order, then lvae_prior_index_f32.  prm, pm and every index bit-equal; and end to end against lvae_gemm_f32 itself: the same GEMM
+    with and without `defer_reduce` (the latter runs the library's own reduce pass)."""
+    import ctypes
+    from lvae import _native
+    from lvae.models.base import pack_f16x2
+    g = torch.Generator().manual_seed(B * HW + z + S)
+    M, N = B * HW, 2 * z
+    ws = (torch.randn(S, M, N, generator=g) * torch.exp(torch.randn(S, 1, 1, generator=g))).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(20.0), 64)).cuda()
+    ref_prm = ws[0].clone()
+    for sl in range(1, S):
+        ref_prm = ref_prm + ws[sl]
+    ref_prm = ref_prm + bias
+    pm0, idx0 = torch.empty(M, z, device='cuda'), torch.empty(B, z, HW, dtype=torch.uint8, device='cuda')
+    assert L.lvae_prior_index_f32(ref_prm.data_ptr(), pm0.data_ptr(), idx0.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, None, _st()) == 0
+    prm = torch.full((M, N), float('nan'), device='cuda')
+    pm1, idx1 = torch.empty(M, z, device='cuda'), torch.empty(B, z, HW, dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert L.lvae_prior_index_sk_f32(ws.data_ptr(), S, bias.data_ptr(), prm.data_ptr(), pm1.data_ptr(), idx1.data_ptr(), table.data_ptr(), 64,
+                                     float(table[0]), B, HW, z, flag.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(prm, ref_prm) and torch.equal(pm1, pm0) and torch.equal(idx1, idx0) and int(flag) == 0
+    # the GEMM itself, K = 512 in S slices: deferred planes + this kernel == the GEMM's own reduce pass + lvae_prior_index_f32
+    if 512 % (32 * S) == 0:
+        K = 512
+        A = torch.randn(M, K, generator=g).cuda()
+        Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        w16 = pack_f16x2(Wt)
+
+        def desc(defer, out, wsb):
+            d = _native.GemmDesc()
+            d.A0, d.lda0, d.K0, d.Wt, d.Wt16, d.ldw = A.data_ptr(), K, K, Wt.data_ptr(), w16.data_ptr(), K
+            d.bias, d.out, d.ldo, d.M, d.N, d.K, d.epi, d.prec = bias.data_ptr(), out.data_ptr(), N, M, N, K, 0, 4
+            d.ksplit, d.ws, d.defer_reduce = S, wsb.data_ptr(), defer
+            return d
+        out_a = torch.full((M, N), float('nan'), device='cuda'); ws_a = torch.empty(S * M * N, device='cuda')
+        out_b = torch.full((M, N), float('nan'), device='cuda'); ws_b = torch.full((S * M * N,), float('nan'), device='cuda')
+        assert L.lvae_gemm_f32(ctypes.byref(desc(0, out_a, ws_a)), _st()) == 0
+        assert L.lvae_gemm_f32(ctypes.byref(desc(1, out_b, ws_b)), _st()) == 0
+        torch.cuda.synchronize()
+        assert torch.isnan(out_b).all() and not torch.isnan(ws_b).any()          # deferred: planes written, no reduce pass
+        assert L.lvae_prior_index_f32(out_a.data_ptr(), pm0.data_ptr(), idx0.data_ptr(), table.data_ptr(), 64, float(table[0]), B, HW, z, None, _st()) == 0
+        assert L.lvae_prior_index_sk_f32(ws_b.data_ptr(), S, bias.data_ptr(), prm.data_ptr(), pm1.data_ptr(), idx1.data_ptr(), table.data_ptr(), 64,
+                                         float(table[0]), B, HW, z, None, _st()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(prm, out_a) and torch.equal(pm1, pm0) and torch.equal(idx1, idx0)
+
+
 def test_prior_index_quantize_dequantize(L):
     """Integer outputs must be EXACT against the reference formulation computed by torch on the same device values
     away from decision boundaries, and against an fp64 evaluation elsewhere."""
