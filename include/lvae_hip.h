@@ -237,7 +237,7 @@ int lvae_gemm_num_configs(void);      /* number of selectable tile configuration
 enum {
     LVAE_OP_GEMM = 1, LVAE_OP_DWCONV_LN_F32, LVAE_OP_DWCONV_LN_H2, LVAE_OP_DWCONV_LN_BF16, LVAE_OP_DWCONV_LN_Q8, LVAE_OP_STEM_F32, LVAE_OP_STEM_BF16,
     LVAE_OP_BIAS_EXPAND_F32, LVAE_OP_BIAS_EXPAND_BF16, LVAE_OP_PRIOR_INDEX, LVAE_OP_QUANTIZE, LVAE_OP_DEQUANTIZE, LVAE_OP_GAUSSIAN_NLL,
-    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_MLP_SK, LVAE_OP_PRIOR_INDEX_SK, LVAE_OP_ORDER
+    LVAE_OP_LOSSLESS_PARAMS, LVAE_OP_LOSSLESS_OUTPUT, LVAE_OP_MLP_H2F, LVAE_OP_MLP_SK, LVAE_OP_PRIOR_INDEX_SK, LVAE_OP_QUANTIZE_SK, LVAE_OP_ORDER
 };
 typedef struct { int kind; int side; void* p[8]; long i[6]; double f[2]; } lvae_op;
 #define LVAE_TRACE_MAGIC 1985229328.0      /* lvae_decode_blocks: seconds[1] of a timeline request */
@@ -360,6 +360,10 @@ int lvae_prior_index_sk_f32(const float* ws, int S, const float* bias, float* pr
  * per image, zhat = float(sym) + pm in NHWC (row stride ldz, see below). */
 int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
                       int* status, void* stream);
+/* The same behind a split-K `posterior` GEMM whose reduce pass was deferred: qm[m][c] = ((ws[0] + ws[1]) + ... + ws[S-1])[m][c] + bias[c]
+ * (planes of [B*HW][z] floats, slice order) is written and quantised in ONE launch. */
+int lvae_quantize_sk_f32(const float* ws, int S, const float* bias, float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW,
+                         int z, int ldz, int* status, void* stream);
 /* status (optional): LVAE_STATUS_NONFINITE_LATENT is OR-ed in when qm - pm is NaN / inf or |rint(qm - pm)| >= 2^31. */
 /* GaussianConditional.dequantize (qarv/model.py:113): zhat = float(sym) + pm; sym in NCHW raster order.
  * In both, zhat rows have stride ldz >= z floats; columns [z, ldz) are written as zeros (lets a following 3x3 conv

@@ -76,6 +76,10 @@ extern "C" int lvae_run_ops(const lvae_op* ops, int n, void* stream, void* side_
                 rc = lvae_prior_index_sk_f32((const float*)p[0], (int)i[0], (const float*)p[1], (float*)p[2], (float*)p[3], (uint8_t*)p[4], (const float*)p[5],
                                              (int)i[1], (float)f[0], (int)i[2], (int)i[3], (int)i[4], (int*)p[6], st);
                 break;
+            case LVAE_OP_QUANTIZE_SK:
+                rc = lvae_quantize_sk_f32((const float*)p[0], (int)i[0], (const float*)p[1], (float*)p[2], (const float*)p[3], (int32_t*)p[4], (float*)p[5],
+                                          (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int*)p[6], st);
+                break;
             case LVAE_OP_ORDER:      // i[0] != 0: the side stream waits for the main stream (fork); else the main stream for the side stream (join)
                 rc = i[0] ? lvae_stream_order(stream, side_stream, p[0]) : lvae_stream_order(side_stream, stream, p[0]);
                 break;

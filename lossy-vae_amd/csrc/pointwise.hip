@@ -467,8 +467,14 @@ __global__ __launch_bounds__(256) void prior_index_kernel(const float* __restric
     }
 }
 
+// SK: the posterior mean is first formed from the S planes of a split-K GEMM whose reduce pass was deferred (as prior_index_kernel<true>)
+// and written to qm_out for the other consumers.
+template <bool SK>
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ qm, const float* __restrict__ pm, int32_t* __restrict__ sym,
-                                                       float* __restrict__ zhat, int HW, int z, int ldz, int* __restrict__ status) {
+                                                       float* __restrict__ zhat, int HW, int z, int ldz, int* __restrict__ status,
+                                                       const float* __restrict__ ws, int S, long plane, const float* __restrict__ bias,
+                                                       float* __restrict__ qm_out) {
+#pragma clang fp contract(off)
     __shared__ int tile[CT_CH * CT_LD];
     const int b = blockIdx.z, p0 = blockIdx.x * CT_PIX, np = (HW - p0) < CT_PIX ? (HW - p0) : CT_PIX;
     const long m0 = (long)b * HW + p0;
@@ -480,7 +486,17 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
             const long m = m0 + pl;
             if (c >= z) { zhat[m * ldz + c] = 0.f; continue; }
             const float mu = pm[m * z + c];
-            const float r = rintf(qm[m * z + c] - mu);  // v_rndne_f32: round-half-to-even == torch.round
+            float q;
+            if constexpr (SK) {
+                const float* w = ws + m * z + c;
+                q = w[0];
+                for (int sl = 1; sl < S; ++sl) q += w[sl * plane];
+                q += bias[c];
+                qm_out[m * z + c] = q;
+            } else {
+                q = qm[m * z + c];
+            }
+            const float r = rintf(q - mu);  // v_rndne_f32: round-half-to-even == torch.round
             if (status && !(fabsf(r) < 2147483648.0f)) atomicOr(status, LVAE_STATUS_NONFINITE_LATENT);      // NaN / inf / no int32 symbol
             zhat[m * ldz + c] = r + mu;
             tile[(c - c0) * CT_LD + pl] = (int32_t)r;
@@ -728,8 +744,16 @@ extern "C" int lvae_prior_index_sk_f32(const float* ws, int S, const float* bias
 extern "C" int lvae_quantize_f32(const float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW, int z, int ldz,
                                  int* status, void* stream) {
     if (!qm || !pm || !sym || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((ldz + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
-                       zhat, HW, z, ldz, status);
+    hipLaunchKernelGGL(quantize_kernel<false>, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((ldz + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream, qm, pm, sym,
+                       zhat, HW, z, ldz, status, (const float*)nullptr, 0, 0L, (const float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lvae_quantize_sk_f32(const float* ws, int S, const float* bias, float* qm, const float* pm, int32_t* sym, float* zhat, int B, int HW,
+                                    int z, int ldz, int* status, void* stream) {
+    if (!ws || S < 2 || !bias || !qm || !pm || !sym || !zhat || B <= 0 || B > 65535 || HW <= 0 || z <= 0 || ldz < z) return -22;
+    hipLaunchKernelGGL(quantize_kernel<true>, dim3((unsigned)((HW + CT_PIX - 1) / CT_PIX), (unsigned)((ldz + CT_CH - 1) / CT_CH), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, pm, sym, zhat, HW, z, ldz, status, ws, S, (long)B * HW * z, bias, qm);
     return (int)hipGetLastError();
 }
 
@@ -845,5 +869,5 @@ extern "C" int lvae_stream_order(void* from_stream, void* to_stream, void* ev) {
     return (int)hipStreamWaitEvent((hipStream_t)to_stream, (hipEvent_t)ev, 0);
 }
 
-extern "C" int lvae_abi_version(void) { return 23; }
+extern "C" int lvae_abi_version(void) { return 24; }
 extern "C" const char* lvae_build_info(void) { return "liblvae_hip gfx950 (MI355X) fp32-MFMA; hipcc " __VERSION__; }

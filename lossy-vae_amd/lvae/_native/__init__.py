@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 
@@ -64,7 +64,7 @@ class EncBlock(C.Structure):
 OP_KINDS = {name: k + 1 for k, name in enumerate([
     'lvae_gemm_f32', 'lvae_dwconv_ln_f32', 'lvae_dwconv_ln_h2', 'lvae_dwconv_ln_bf16', 'lvae_dwconv_ln_q8', 'lvae_stem_f32', 'lvae_stem_bf16',
     'lvae_bias_expand_f32', 'lvae_bias_expand_bf16', 'lvae_prior_index_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32',
-    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f', 'lvae_mlp_sk', 'lvae_prior_index_sk_f32'])}
+    'lvae_gaussian_nll_f32', 'lvae_lossless_params_f32', 'lvae_lossless_output_f32', 'lvae_mlp_h2f', 'lvae_mlp_sk', 'lvae_prior_index_sk_f32', 'lvae_quantize_sk_f32'])}
 OP_ORDER = len(OP_KINDS) + 1
 
 TRACE_MAGIC = 1985229328.0       # LVAE_TRACE_MAGIC
@@ -102,6 +102,7 @@ SIGNATURES = {
     'lvae_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_prior_index_f32': (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
     'lvae_prior_index_sk_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
+    'lvae_quantize_sk_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lvae_quantize_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'lvae_dequantize_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'lvae_lossless_params_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),

@@ -257,7 +257,7 @@ class CodecBase(nn.Module):
     def _alias_host(pl, seg, n_ops):
         """A copy of a native segment whose launches address pl.sym_host / pl.idx_host wherever the recorded ones address pl.sym_all / pl.idx_all."""
         from .. import _native
-        raster_ops = {_native.OP_KINDS[k] for k in ('lvae_prior_index_f32', 'lvae_prior_index_sk_f32', 'lvae_quantize_f32', 'lvae_dequantize_f32')}
+        raster_ops = {_native.OP_KINDS[k] for k in ('lvae_prior_index_f32', 'lvae_prior_index_sk_f32', 'lvae_quantize_f32', 'lvae_quantize_sk_f32', 'lvae_dequantize_f32')}
         spans = [(pl.sym_all.data_ptr(), pl.sym_all.numel() * 4, pl.sym_host.data_ptr()), (pl.idx_all.data_ptr(), pl.idx_all.numel(), pl.idx_host.data_ptr())]
         out = (_native.Op * max(1, n_ops))()
         ctypes.memmove(out, seg, ctypes.sizeof(_native.Op) * n_ops)

@@ -419,14 +419,18 @@ class _EncPlan(_NetPlan):
                           label=p + '.post_merge')
                 self.cnx(p + '.posterior2', m.posterior2, mg.data_ptr(), mg.data_ptr(), h, w)
                 qm = self.buf('qm', M * z)
-                self.gemm(A0=mg.data_ptr(), K0=m.width, M=M, N=z, K=9 * m.width, Wt=pk.p(p + '.posterior.w'),
-                          bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w, out_bf16=0,
-                          label=p + '.posterior')
+                planes = self.gemm(A0=mg.data_ptr(), K0=m.width, M=M, N=z, K=9 * m.width, Wt=pk.p(p + '.posterior.w'),
+                                   bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w, out_bf16=0,
+                                   defer_reduce=(self.prec != 3), label=p + '.posterior')
                 zhat = self.buf('zhat', M * z)
                 self.qm_bufs.append(qm); self.zhat_bufs.append(zhat); self.zhat_ld.append(z)
                 self.sym_off.append(ioff)
-                self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
-                                                 B, h * w, z, z, self.status_ptr()), p + '.quantize')
+                if planes:      # split-K planes of the posterior head: summed (slice order, + bias) by the quantize launch itself
+                    self.add(lib.lvae_quantize_sk_f32, (planes[0], planes[1], pk.p(p + '.posterior.b'), qm.data_ptr(), pm.data_ptr(),
+                                                        ptr(self.sym_all, ioff), zhat.data_ptr(), B, h * w, z, z, self.status_ptr()), p + '.quantize')
+                else:
+                    self.add(lib.lvae_quantize_f32, (qm.data_ptr(), pm.data_ptr(), ptr(self.sym_all, ioff), zhat.data_ptr(),
+                                                     B, h * w, z, z, self.status_ptr()), p + '.quantize')
                 self.qcuts.append(len(self.ops))        # this block's symbols and indexes are final from here on
                 if with_bits:       # eval-mode likelihood of the quantised latent (qarv/model.py:95-96), prm still holds this block
                     li = len(self.sym_off) - 1

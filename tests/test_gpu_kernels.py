@@ -360,6 +360,39 @@ def test_prior_index_behind_a_deferred_split_k_reduce(L, B, HW, z, S):
         assert torch.equal(prm, out_a) and torch.equal(pm1, pm0) and torch.equal(idx1, idx0)
 
 
+@pytest.mark.parametrize('B,HW,z,ldz,S', [(3, 35, 32, 32, 4), (1, 96, 32, 32, 36), (2, 1536, 96, 96, 9), (4, 6144, 8, 32, 4), (1, 70, 16, 32, 7)])
+def test_quantize_behind_a_deferred_split_k_reduce(L, B, HW, z, ldz, S):
+    """lvae_quantize_sk_f32 (round 6): the posterior mean formed from the S planes of a split-K GEMM whose reduce pass was deferred, then
+    quantised, against the two-launch form (the sum done by torch in slice order, then lvae_quantize_f32): qm, symbols and zhat bit-equal,
+    padded zhat columns zeroed, and the non-finite flag raised by a NaN that only appears in the sum."""
+    g = torch.Generator().manual_seed(B * HW + z + S)
+    M = B * HW
+    ws = (torch.randn(S, M, z, generator=g) * 3.0).cuda()
+    bias = torch.randn(z, generator=g).cuda()
+    pm = torch.randn(M, z, generator=g).cuda()
+    ref_qm = ws[0].clone()
+    for sl in range(1, S):
+        ref_qm = ref_qm + ws[sl]
+    ref_qm = ref_qm + bias
+    sym0 = torch.empty(B, z, HW, dtype=torch.int32, device='cuda'); zh0 = torch.full((M, ldz), float('nan'), device='cuda')
+    assert L.lvae_quantize_f32(ref_qm.data_ptr(), pm.data_ptr(), sym0.data_ptr(), zh0.data_ptr(), B, HW, z, ldz, None, _st()) == 0
+    qm = torch.full((M, z), float('nan'), device='cuda')
+    sym1 = torch.empty(B, z, HW, dtype=torch.int32, device='cuda'); zh1 = torch.full((M, ldz), float('nan'), device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert L.lvae_quantize_sk_f32(ws.data_ptr(), S, bias.data_ptr(), qm.data_ptr(), pm.data_ptr(), sym1.data_ptr(), zh1.data_ptr(), B, HW, z, ldz,
+                                  flag.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(qm, ref_qm) and torch.equal(sym1, sym0) and torch.equal(zh1, zh0) and int(flag) == 0
+    assert (zh1[:, z:] == 0).all()
+    ws[0, 0, 0], ws[S - 1, 0, 0] = float('inf'), float('-inf')              # finite planes apart, NaN in the sum
+    assert L.lvae_quantize_sk_f32(ws.data_ptr(), S, bias.data_ptr(), qm.data_ptr(), pm.data_ptr(), sym1.data_ptr(), zh1.data_ptr(), B, HW, z, ldz,
+                                  flag.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    assert int(flag) != 0 and torch.isnan(qm[0, 0])
+    assert L.lvae_quantize_sk_f32(ws.data_ptr(), 1, bias.data_ptr(), qm.data_ptr(), pm.data_ptr(), sym1.data_ptr(), zh1.data_ptr(), B, HW, z, ldz,
+                                  None, _st()) == -22
+
+
 def test_prior_index_quantize_dequantize(L):
     """Integer outputs must be EXACT against the reference formulation computed by torch on the same device values
     away from decision boundaries, and against an fp64 evaluation elsewhere."""
