@@ -1,6 +1,6 @@
 """Host-side timeline of decompress_batch (bench workload, product configuration), unprofiled: per pipeline group and latent block the
 stamps lvae_decode_blocks records (segment launch begins / issued / indexes on the host / block decoded), relative to the call's entry,
-averaged over the steps.   python tools/dec_timeline.py [B=8] [steps=20]"""
+averaged over the steps.   python tools/dec_timeline.py [B=8] [steps=20] [typical|calibrated]"""
 import os
 import sys
 import time
@@ -21,8 +21,15 @@ dev = torch.device('cuda', 0)
 model, sd = bench.build_model(dev)
 model.coder_threads = max(8, len(os.sched_getaffinity(0)))
 ims = bench.synth_batch(B, 512, 768, 0).to(dev)
+kind = sys.argv[3] if len(sys.argv) > 3 else 'typical'
+if kind == 'calibrated':           # latents drawn from the model's own prior (lossy-vae_amd/coder_workloads.py)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'lossy-vae_amd'))
+    import coder_workloads as cw  # noqa: E402
+    s = cw.calibrated_strings(model, B, 8, 12, seed=1)[0]
+else:
+    s = model.compress_batch(ims)
 for _ in range(4):
-    s = model.compress_batch(ims); torch.cuda.synchronize(); model.decompress_batch(s); torch.cuda.synchronize()
+    torch.cuda.synchronize(); model.decompress_batch(s); torch.cuda.synchronize()
 rows = []
 tot = 0.0
 for _ in range(steps):
@@ -36,7 +43,7 @@ for _ in range(steps):
     tr = sorted(model.dec_trace, key=lambda r: r[2][2])          # groups by their first stamp
     rows.append((t_ret - t0, t1 - t0, [[v - t0 for v in r[2][2:2 + 4 * r[1] + 1]] for r in tr]))
 model.dec_trace = None
-print(f'B={B}: decompress_batch + sync {tot / steps * 1e3:.3f} ms per step; returns at {np.mean([r[0] for r in rows]) * 1e3:.3f} ms')
+print(f'B={B} ({kind} strings): decompress_batch + sync {tot / steps * 1e3:.3f} ms per step; returns at {np.mean([r[0] for r in rows]) * 1e3:.3f} ms')
 ng = len(rows[0][2])
 for g in range(ng):
     a = np.mean([r[2][g] for r in rows], axis=0) * 1e3
