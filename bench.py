@@ -140,6 +140,8 @@ def launch_class(fn, a):
         return f'prec {d.prec} GEMM'
     if d.a_h2:
         return 'gemm_h2p FOLD (pre-split operands, serial split-K)' if d.ksplit > 1 else 'gemm_h2p (pre-split operands)'
+    if d.ksplit > 1 and d.defer_reduce:       # prior / posterior heads: the planes are summed by lvae_prior_index_sk_f32 / lvae_quantize_sk_f32
+        return 'gemm_h2 split-K, planes summed by the consumer launch (prior / posterior heads)'
     return 'gemm_h2 (fp32 A split in the main loop)' + (' + split-K reduce' if d.ksplit > 1 else '')
 
 
