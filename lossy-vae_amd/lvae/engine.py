@@ -256,6 +256,8 @@ class Plan:
         """Scratch buffers of side-stream ops are separate from the main stream's (they run concurrently)."""
         return name + '_side' if self.on_side else name
 
+    DEFER_MAX_PLANES = 16              # ... up to this many planes (the consumer has few workgroups: 36 planes cost a single-image encode 1.6 %)
+    DEFER_HEAD_REDUCE = True           # prior / posterior heads leave their split-K planes to the index / quantize launch (False: reduce launch; A/B tool, same bits)
     use_q8_pipeline = True             # reduced-precision plans: producer-side quantisation (False: the in-GEMM quantiser everywhere; A/B tool)
     H2P_MIN_ROWS_PER_IMAGE = 1536      # stride-4 / 8 / 16 maps of a 512x768 image; below, the few-tile layers want split-K (gemm_h2.hip)
 
@@ -363,7 +365,8 @@ class Plan:
         deferred = None
         if ksplit > 1 and a_h2:
             d.ksplit = ksplit                                      # serial form: no workspace, no reduce launch
-        elif ksplit > 1 and defer_reduce and epi == _native.EPI_BIAS and store == _native.ST_ROWMAJOR and d.ldo == N and bias:
+        elif (1 < ksplit <= self.DEFER_MAX_PLANES and defer_reduce and epi == _native.EPI_BIAS and store == _native.ST_ROWMAJOR
+              and d.ldo == N and bias):
             # (a workspace of its own name: the consumer launch follows at once, on the same stream)
             d.ksplit, d.ws, d.defer_reduce = ksplit, self.buf(self.sname('deferred_ws'), ksplit * M * N).data_ptr(), 1
             deferred = (d.ws, ksplit)

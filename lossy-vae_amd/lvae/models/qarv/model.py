@@ -290,7 +290,7 @@ class _NetPlan(Plan):
         prm = self.buf('prm', M * 2 * z)
         # (split-K launches leave their reduce pass to the index kernel: one launch less per latent block on both chains, same bits)
         planes = self.gemm(A0=f, K0=m.width, M=M, N=2 * z, Wt=pk.p(p + '.prior.w'), bias=pk.p(p + '.prior.b'),
-                           out=prm.data_ptr(), out_bf16=0, defer_reduce=(self.prec != 3), label=p + '.prior')
+                           out=prm.data_ptr(), out_bf16=0, defer_reduce=(self.prec != 3 and self.DEFER_HEAD_REDUCE), label=p + '.prior')
         pm = self.new(M * z)
         self.pm_bufs.append(pm)
         self.prm_ptrs.append(prm.data_ptr())
@@ -421,7 +421,7 @@ class _EncPlan(_NetPlan):
                 qm = self.buf('qm', M * z)
                 planes = self.gemm(A0=mg.data_ptr(), K0=m.width, M=M, N=z, K=9 * m.width, Wt=pk.p(p + '.posterior.w'),
                                    bias=pk.p(p + '.posterior.b'), out=qm.data_ptr(), a_mode=_native.A_CONV3, H=h, W=w, out_bf16=0,
-                                   defer_reduce=(self.prec != 3), label=p + '.posterior')
+                                   defer_reduce=(self.prec != 3 and self.DEFER_HEAD_REDUCE), label=p + '.posterior')
                 zhat = self.buf('zhat', M * z)
                 self.qm_bufs.append(qm); self.zhat_bufs.append(zhat); self.zhat_ld.append(z)
                 self.sym_off.append(ioff)
