@@ -3,6 +3,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 from lvae import _native
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,3 +53,25 @@ def test_argument_validation_without_gpu():
     assert L.lvae_gemv_f32(None, None, None, None, 4, 4, 0, 0, None) == -22
     assert L.lvae_stem_f32(None, None, None, None, 1, 64, 64, 192, 0.0, 1.0, None, None) == -22
     assert L.lvae_range_flag_f32(None, 16, 0.0, 1.0, None, None) == -22
+
+
+def test_c99_client_round_trips_the_coder(tmp_path):
+    """The boundary from C: tests/c_client/coder_roundtrip.c includes include/lvae_hip.h as pedantic C99 (no C++ in the header), links
+    liblvae_hip.so and round-trips 100 000 symbols (escapes included) through lvae_build_gaussian_tables / lvae_rans_encode_with_indexes /
+    lvae_rans_decode_with_indexes, then checks the documented error codes (-2 short buffer, -4 bad index, < 0 truncated stream)."""
+    import shutil
+    import subprocess
+    from lvae import _native
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc on this host')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(os.path.abspath(_native.LIB_PATH))
+    exe = str(tmp_path / 'coder_rt')
+    cc = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-O1', '-I' + os.path.join(root, 'include'),
+                         os.path.join(root, 'tests', 'c_client', 'coder_roundtrip.c'), '-o', exe, '-L' + libdir, '-l:' + os.path.basename(_native.LIB_PATH),
+                         '-lm', '-Wl,-rpath,' + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    tag, abi, nbytes = run.stdout.split()
+    assert tag == 'ok' and int(abi) == _native.ABI_VERSION and int(nbytes) > 8
