@@ -32,7 +32,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LVAE_FENCE() __builtin_amdgcn_sched_barrier(0)
 // timing ablations (wrong results by construction; tools/build_exp.sh only): what a launch costs without its MFMAs / fragment reads / epilogue
-#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2P_EXP_NOMFMA) || defined(H2P_EXP_NODSR) || defined(H2P_EXP_NOEPI) || defined(H2P_EXP_NODMA) || defined(H2P_EXP_STAGGER3))
+#if !defined(LVAE_EXPERIMENTAL_BUILD) && (defined(H2P_EXP_NOMFMA) || defined(H2P_EXP_NODSR) || defined(H2P_EXP_NOEPI) || defined(H2P_EXP_NODMA))
 #error "H2P_EXP_* ablations need -DLVAE_EXPERIMENTAL_BUILD (tools/build_exp.sh)"
 #endif
 #ifdef H2P_EXP_NODSR
@@ -85,26 +85,12 @@ __global__ __launch_bounds__(128 * WM + 64 * NLOAD, (NLOAD ? 1 : (WM == 4 ? 1 : 
     // alternates between main loops (matrix pipe busy, HBM nearly idle) and epilogues (every CU storing its tile, the matrix pipe idle).
     // Starting every second workgroup half a main loop late -- the second resident workgroup of a CU (told by its LDS allocation
     // base) or, with one workgroup per CU, the odd CUs -- was measured and did NOT help (0 ... -5 %): kept as a knob for the record.
-#ifdef H2P_EXP_STAGGER3
-    // round 6 study (tools/r6_stagger3.sh; experimental builds only): the dispatcher fills the chip in LAYERS -- workgroup b of the first
-    // 256 x RES lands in slot (b / 8) / 32 of its CU (tools/ubench/lds_slot_probe.hip: 256 of 256 CUs) -- so the first generation can be started
-    // in RES phases, slot l delayed by l x nq x stagger x 64 cycles; later workgroups inherit the phase of the slot they take over.
-    if (stagger > 0) {
-        constexpr int RES = NLOAD ? 1 : (WM == 4 ? 1 : (NBUF == 2 && TN == 1 ? 3 : 2));
-        const int b = blockIdx.x;
-        if (RES > 1 && b < 256 * RES) {
-            const int layer = (b >> 3) >> 5;
-            for (int i = 0; i < layer * nq * stagger; ++i) __builtin_amdgcn_s_sleep(1);
-        }
-    }
-#else
     if (stagger > 0) {
         const bool late = WM == 4 ? ((__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4) & 1) != 0)          // HW_ID.CU_ID bit 0
                                   : (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 6) != 0);                // LDS_ALLOC.LDS_BASE
         if (late)
             for (int i = 0; i < nq * stagger; ++i) __builtin_amdgcn_s_sleep(8);        // 512 cycles each
     }
-#endif
 
     // ---- DMA side.  Wave w issues the stage's instructions g = i * NWAVE + w (i < NI): rows 8g .. 8g + 7 of the stage (A rows first).
     const int rows_a = (d.M - m0) < BM ? (d.M - m0) : BM, rows_w = (d.N - n0) < BN ? (d.N - n0) : BN;
