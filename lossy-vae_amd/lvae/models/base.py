@@ -506,9 +506,14 @@ class CodecBase(nn.Module):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))        # lambda tables / inputs produced on the caller's stream
 
+        stagger = float(getattr(self, 'group_stagger_s', 0.0) or 0.0)       # study knob (tools/r6_stagger_groups.py): group g starts g x this later
+
         def work(g):
             st = self._streams[g]
             st.wait_event(ev)
+            if stagger > 0.0 and g:
+                import time as _t
+                _t.sleep(g * stagger)              # (sleep, not a spin: a spinning Python thread keeps the GIL from the other groups' threads)
             with torch.cuda.stream(st):
                 return fn(g, groups[g][0], groups[g][1], st)
         # the last group runs on the calling thread (no hand-over latency for it; the pool threads have theirs first)

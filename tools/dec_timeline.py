@@ -20,6 +20,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device('cuda', 0)
 model, sd = bench.build_model(dev)
 model.coder_threads = max(8, len(os.sched_getaffinity(0)))
+if os.environ.get('DEC_GROUPS'):          # number of pipeline groups (default: the product's rule)
+    model.dec_groups = int(os.environ['DEC_GROUPS'])
 ims = bench.synth_batch(B, 512, 768, 0).to(dev)
 kind = sys.argv[3] if len(sys.argv) > 3 else 'typical'
 if kind == 'calibrated':           # latents drawn from the model's own prior (lossy-vae_amd/coder_workloads.py)
