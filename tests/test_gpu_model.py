@@ -463,3 +463,38 @@ def test_native_group_loops_equal_the_python_loops(product_model):
     finally:
         m.native_group_loops = True
 
+
+
+def test_launch_forms_never_change_a_byte(product_model, qarv_seeded_sd):
+    """Round 6's launch forms are choices of HOW, never of WHAT: a second model whose plans are built without the fused small-map MLP
+    (Plan.MLP_SK_MAX_ROWS = 0: fc1 / fc2 as split-K GEMM launches) and with the heads' own reduce launches (Plan.DEFER_HEAD_REDUCE = False)
+    writes the same byte strings and decodes the same bits as the product configuration -- at a ragged size whose stride-64 map has 35 rows
+    per image, at 512x768, single images and a batch of three."""
+    import lvae
+    from conftest import load_seeded_into
+    from lvae import engine
+    saved = (engine.Plan.MLP_SK_MAX_ROWS, engine.Plan.DEFER_HEAD_REDUCE)
+    try:
+        engine.Plan.MLP_SK_MAX_ROWS, engine.Plan.DEFER_HEAD_REDUCE = 0, False
+        m2 = lvae.get_model('qarv_base')
+        load_seeded_into(m2, qarv_seeded_sd)
+        m2 = m2.to('cuda:0')
+        m2.eval()
+        m2.compress_mode()
+        for (h, w, nb) in ((300, 420, 3), (512, 768, 1), (512, 768, 3)):
+            ims = torch.cat([_img(h, w, 90 + i) for i in range(nb)], 0).cuda()
+            pad_h, pad_w = (h + 63) // 64 * 64, (w + 63) // 64 * 64
+            ims = torch.nn.functional.pad(ims, (0, pad_w - w, 0, pad_h - h), mode='replicate')
+            s2 = m2.compress_batch(ims, 400.0)            # (plans of this size are built here, under the switched-off forms)
+            x2 = m2.decompress_batch(s2).clone()
+            engine.Plan.MLP_SK_MAX_ROWS, engine.Plan.DEFER_HEAD_REDUCE = saved
+            s1 = product_model.compress_batch(ims, 400.0)
+            assert s1 == s2
+            assert torch.equal(product_model.decompress_batch(s1), x2) and torch.equal(m2.decompress_batch(s1), x2)
+            engine.Plan.MLP_SK_MAX_ROWS, engine.Plan.DEFER_HEAD_REDUCE = 0, False
+        kinds2 = {getattr(fn, 'lvae_name', '') for pl in m2._plans.values() for fn, _a, _l, _s in pl.ops if callable(fn)}
+        kinds1 = {getattr(fn, 'lvae_name', '') for pl in product_model._plans.values() for fn, _a, _l, _s in pl.ops if callable(fn)}
+        assert 'lvae_mlp_sk' not in kinds2 and 'lvae_prior_index_sk_f32' not in kinds2 and 'lvae_quantize_sk_f32' not in kinds2
+        assert {'lvae_mlp_sk', 'lvae_prior_index_sk_f32', 'lvae_quantize_sk_f32'} <= kinds1
+    finally:
+        engine.Plan.MLP_SK_MAX_ROWS, engine.Plan.DEFER_HEAD_REDUCE = saved
