@@ -256,7 +256,7 @@ class Plan:
         """Scratch buffers of side-stream ops are separate from the main stream's (they run concurrently)."""
         return name + '_side' if self.on_side else name
 
-    DEFER_MAX_PLANES = 16              # ... up to this many planes (the consumer has few workgroups: 36 planes cost a single-image encode 1.6 %)
+    DEFER_MAX_PLANES = 8               # ... up to this many planes (in situ, B = 1: 4 planes -5 us per block, 9 planes +7 us, 36 planes +30 us against the reduce launch)
     DEFER_HEAD_REDUCE = True           # prior / posterior heads leave their split-K planes to the index / quantize launch (False: reduce launch; A/B tool, same bits)
     use_q8_pipeline = True             # reduced-precision plans: producer-side quantisation (False: the in-GEMM quantiser everywhere; A/B tool)
     H2P_MIN_ROWS_PER_IMAGE = 1536      # stride-4 / 8 / 16 maps of a 512x768 image; below, the few-tile layers want split-K (gemm_h2.hip)
