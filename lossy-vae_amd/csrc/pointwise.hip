@@ -244,7 +244,7 @@ int dispatch_dwln_bf16(int C, const void* x, const float* wt, const float* bias,
 // checked on the values this kernel loads anyway: bit 0 of *range_flag is set when any pixel is outside [0, 1] or NaN; the host
 // reads the flag at a synchronisation point it already has (no extra device sync, unlike the reference's .min()/.max()).
 template <bool BF>
-__global__ void stem_kernel(const float* __restrict__ im, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ im, const float* __restrict__ wt, const float* __restrict__ bias,
                             void* __restrict__ out, int B, int H, int W, int Cout, float im_shift, float im_scale, long M,
                             int* __restrict__ range_flag) {
     __shared__ __attribute__((aligned(16))) float patch[64][48];
@@ -274,20 +274,30 @@ __global__ void stem_kernel(const float* __restrict__ im, const float* __restric
     for (int k = 0; k < 48; ++k) wr[k] = wt[k * Cout + n];
     const float bv = bias[n];
     __syncthreads();
-    for (int p = 0; p < 64; ++p) {
-        const long pg = p0 + p;
-        if (pg >= M) break;
-        float a = bv;
+    // four pixels at a time: four independent 48-FMA chains per thread (one chain alone runs at the FMA's latency, not its rate); per
+    // output the chain is unchanged -- bias, then k ascending -- so the bits are (round 6: 35 -> 14 us for one 512x768 image)
+    for (int p = 0; p < 64; p += 4) {
+        if (p0 + p >= M) break;
+        float a[4] = {bv, bv, bv, bv};
 #pragma unroll
         for (int k4 = 0; k4 < 12; ++k4) {
-            const f32x4 pv = *(const f32x4*)&patch[p][k4 * 4];
-            a = fmaf(pv[0], wr[k4 * 4 + 0], a);
-            a = fmaf(pv[1], wr[k4 * 4 + 1], a);
-            a = fmaf(pv[2], wr[k4 * 4 + 2], a);
-            a = fmaf(pv[3], wr[k4 * 4 + 3], a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 pv = *(const f32x4*)&patch[p + q][k4 * 4];
+                a[q] = fmaf(pv[0], wr[k4 * 4 + 0], a[q]);
+                a[q] = fmaf(pv[1], wr[k4 * 4 + 1], a[q]);
+                a[q] = fmaf(pv[2], wr[k4 * 4 + 2], a[q]);
+                a[q] = fmaf(pv[3], wr[k4 * 4 + 3], a[q]);
+            }
         }
-        if (BF) ((unsigned short*)out)[pg * Cout + n] = (unsigned short)f2bf(a);
-        else ((float*)out)[pg * Cout + n] = a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long pg = p0 + p + q;
+            if (pg < M) {
+                if (BF) ((unsigned short*)out)[pg * Cout + n] = (unsigned short)f2bf(a[q]);
+                else ((float*)out)[pg * Cout + n] = a[q];
+            }
+        }
     }
 }
 
