@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ im,
     const float bv = bias[n];
     __syncthreads();
     // four pixels at a time: four independent 48-FMA chains per thread (one chain alone runs at the FMA's latency, not its rate); per
-    // output the chain is unchanged -- bias, then k ascending -- so the bits are (round 6: 35 -> 14 us for one 512x768 image)
+    // output the chain is unchanged -- bias, then k ascending -- so the bits are (round 6: 35 -> 29 us for one 512x768 image)
     for (int p = 0; p < 64; p += 4) {
         if (p0 + p >= M) break;
         float a[4] = {bv, bv, bv, bv};
