@@ -553,10 +553,12 @@ def main():
     barrier()
     t0 = time.time()
     t_enc = 0.0
+    per_step = []                                          # (encode s, decode s) of every timed step: diagnostics beside the contract's mean
     for _ in range(args.steps):
         ts = time.time()
         strings, out, t_mid = step()
         t_enc += t_mid - ts
+        per_step.append((t_mid - ts, time.time() - t_mid))
     barrier()
     dt = time.time() - t0
     if dist is not None:
@@ -897,6 +899,12 @@ def main():
                        'lambda': model.default_lmb},
             'enc_ms_per_step': round(t_enc / args.steps * 1e3, 3),
             'dec_ms_per_step': round((dt - t_enc) / args.steps * 1e3, 3),
+            # the timed steps one by one (this rank): `value` is the contract's mean over all of them; a host hiccup shows here as max >> median
+            'step_spread': {'enc_ms': {'median': round(float(np.median([e for e, _ in per_step])) * 1e3, 3), 'min': round(min(e for e, _ in per_step) * 1e3, 3),
+                                       'max': round(max(e for e, _ in per_step) * 1e3, 3)},
+                            'dec_ms': {'median': round(float(np.median([d_ for _, d_ in per_step])) * 1e3, 3), 'min': round(min(d_ for _, d_ in per_step) * 1e3, 3),
+                                       'max': round(max(d_ for _, d_ in per_step) * 1e3, 3)},
+                            'slowest_steps': sorted(range(len(per_step)), key=lambda i: -(per_step[i][0] + per_step[i][1]))[:3]},
             'bpp': round(bpp, 4), 'psnr_db': round(-10 * np.log10(mse), 3),
             'ref_3080ti_mpx_s': 2.47,
             'roofline': roof, 'roofline_e2e': roofline_e2e, 'fp32_mfma_mode_value': fp32_mode, 'bf16x3_mode_value': bf16x3_mode,
