@@ -456,7 +456,7 @@ def test_bench_line_carries_a_measured_roofline(offline_home, tmp_path):
     assert all('error' not in v and v['value'] > 0 for v in j['other_sizes'].values()), j['other_sizes']
     sp = j['step_spread']            # the timed steps one by one beside the contract's mean: min <= median <= max, the mean inside [min, max]
     for k, mean in (('enc_ms', j['enc_ms_per_step']), ('dec_ms', j['dec_ms_per_step'])):
-        assert 0 < sp[k]['min'] <= sp[k]['median'] <= sp[k]['max'] and sp[k]['min'] - 0.01 <= mean <= sp[k]['max'] + 0.01, (k, sp[k], mean)
+        assert 0 < sp[k]['min'] <= sp[k]['median'] <= sp[k]['max'] and sp[k]['min'] - 0.05 <= mean <= sp[k]['max'] + 0.05, (k, sp[k], mean)
 
 
 # ------------------------------------------------------------------------------------------------------------------ H2, f2
