@@ -15,9 +15,13 @@
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 __global__ __launch_bounds__(256) void sum_kernel(const int* p, int n, unsigned long long* out) {
+    __shared__ unsigned long long part[256];
     unsigned long long s = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += (unsigned)p[i];
-    atomicAdd(out, s);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(out, part[0]);          // (one atomic per workgroup: `out` is pinned host memory)
 }
 
 int main(int argc, char** argv) {
@@ -60,8 +64,12 @@ int main(int argc, char** argv) {
         __builtin_ia32_sfence();
         const double t1 = now_us();
         *out = 0;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
         hipLaunchKernelGGL(sum_kernel, dim3(96), dim3(256), 0, st, dev, n, out);
-        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float kms; CK(hipEventElapsedTime(&kms, e0, e1));
+        printf("  (kernel reading the freshly stored words: %.1f us)\n", kms * 1e3);
         unsigned long long want = 0;
         for (int i = 0; i < n; ++i) want += (unsigned)((i * 7 + rep) & 1023);
         printf("  %d sequential 4-byte stores: %.1f us = %.2f GB/s; kernel sees them: %s\n", n, t1 - t0, n * 4 / (t1 - t0) / 1e3, *out == want ? "yes" : "NO");
